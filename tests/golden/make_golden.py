@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference; the GPU box has no reference).
+The reference modules are imported unmodified; three absent third-party packages are
+replaced by the test-only stand-ins in tests/golden/ref_shims (see its README).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz and prints oracle-vs-reference errors
+
+What is recorded (inputs are regenerated from seeds by matcha-tts-24k_amd/synthetic.py, so
+only small id arrays and expected outputs are stored):
+  tiny_encoder.npz   B=2 ragged: TextEncoder.forward outputs (reference text_encoder.py:375)
+  tiny_decoder.npz   B=2 ragged mask: Decoder.forward for t in {0, 0.37} (reference decoder.py:359)
+  tiny_synth.npz     per-utterance MatchaTTSInfer.synthesise (reference inference.py:78) for euler/2,
+                     midpoint/2, rk4/1 + a batched composition of the reference's own components
+  prod_synth.npz     prod v20 shapes, Tx=128: logw, mu_y, 1-NFE decoder output, mel for euler/2, euler/10, midpoint/4
+  prod_batch.npz     prod shapes, B=3 ragged lengths, euler/2 (reference components composed as synthesise does)
+  randn42.npz        first values of the CPU seed-42 normal stream (detects an RNG mismatch on another box)
+"""
+import importlib
+import os
+import sys
+import types
+from pathlib import Path
+
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REF = Path("/root/reference")
+
+import numpy as np
+import torch
+
+torch.manual_seed(0)
+
+
+def import_reference():
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(HERE / "ref_shims"))
+    for name, attrs in {
+        "av": {},
+        "matcha.text.phonemizers": {"multilingual_phonemizer": None},
+        "matcha.utils.mp3_converter": {"encode_mp3": None},
+        "matcha.vocos24k.vocos_wrapper": {"load_model": None},
+    }.items():
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    import matcha.inference as ref_inf  # noqa: E402
+    return ref_inf
+
+
+def load_pkg():
+    sys.path.insert(0, str(ROOT))
+    return importlib.import_module("matcha-tts-24k_amd")
+
+
+def build_ref_model(ref_inf, hp, sd):
+    model = ref_inf.MatchaTTSInfer(**hp.as_reference_kwargs())
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "rope" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    model.eval()
+    model.decoder.solver = hp.solver
+    return model
+
+
+def maxabs(a, b):
+    return float((a - b).abs().max())
+
+
+@torch.inference_mode()
+def main():
+    ref_inf = import_reference()
+    pkg = load_pkg()
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import matcha_oracle as O
+    hparams = importlib.import_module("matcha-tts-24k_amd.hparams")
+    synthetic = importlib.import_module("matcha-tts-24k_amd.synthetic")
+    from matcha.utils.model import sequence_mask, generate_path, downsample, fix_len_compatibility, denormalize
+
+    report = {}
+
+    # ------------------------------------------------------------------ tiny
+    hp = hparams.tiny(n_spks=2)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    model = build_ref_model(ref_inf, hp, sd)
+    x, x_len, spk = synthetic.make_inputs(hp, 2, 12, seed=1234, lengths=[12, 9])
+    e_enc = model.speaker_embeddings_enc(spk)
+    e_dur = model.speaker_embeddings_dur(spk)
+    mu_x, logw, x_mask = model.encoder(x, x_len, e_enc, e_dur)
+    o_mu, o_logw, o_mask = O.text_encoder_forward(sd, hp, x, x_len, sd["speaker_embeddings_enc.weight"][spk],
+                                                  sd["speaker_embeddings_dur.weight"][spk])
+    report["tiny.encoder.mu_x"] = maxabs(mu_x, o_mu)
+    report["tiny.encoder.logw"] = maxabs(logw, o_logw)
+    np.savez(HERE / "tiny_encoder.npz", x=x.numpy(), x_lengths=x_len.numpy(), speakers=spk.numpy(),
+             mu_x=mu_x.numpy(), logw=logw.numpy(), x_mask=x_mask.numpy())
+
+    # decoder alone, ragged mask, two times
+    T = 24
+    nf = hp.n_feats
+    xin = torch.from_numpy(synthetic.portable_normal(11, 1, 2 * nf * T).reshape(2, nf, T))
+    mu = torch.from_numpy(synthetic.portable_normal(11, 2, 2 * nf * T).reshape(2, nf, T))
+    lens = torch.tensor([24, 13])
+    mask = sequence_mask(lens, T).unsqueeze(1).float()
+    outs = {}
+    for tv in (0.0, 0.37):
+        t = torch.tensor(tv)
+        v = model.decoder.estimator(xin, mask, mu, t)
+        ov = O.decoder_forward(sd, hp, xin, mask, mu, t)
+        report[f"tiny.decoder.t{tv}"] = maxabs(v, ov)
+        outs[f"v_t{tv}"] = v.numpy()
+    np.savez(HERE / "tiny_decoder.npz", lengths=lens.numpy(), T=np.array(T), **outs)
+
+    # full synthesise, per utterance (the reference is batch-1 only, inference.py:118-121)
+    rec = {}
+    for solver, steps in (("euler", 2), ("midpoint", 2), ("rk4", 1)):
+        model.decoder.solver = solver
+        for b in range(2):
+            xb = x[b:b + 1, : int(x_len[b])]
+            out = model.synthesise(xb, x_len[b:b + 1], n_timesteps=steps, speaker=int(spk[b]), scale_correction=1.03,
+                                   length_scale=0.9, debug=True)
+            oo = O.synthesise(sd, hp, xb, x_len[b:b + 1], steps, speaker=int(spk[b]), scale_correction=1.03,
+                              length_scale=0.9, solver=solver)
+            report[f"tiny.synth.{solver}{steps}.b{b}"] = maxabs(out["mel"], oo["mel"])
+            rec[f"mel_{solver}{steps}_b{b}"] = out["mel"].numpy()
+            rec[f"dur_b{b}"] = out["phoneme_durations"].numpy()
+    # voice mix
+    model.decoder.solver = "euler"
+    mix = [(0, 0.7), (1, 0.3)]
+    out = model.synthesise(x[:1], x_len[:1], n_timesteps=2, voice_mix=mix)
+    oo = O.synthesise(sd, hp, x[:1], x_len[:1], 2, voice_mix=mix, solver="euler")
+    report["tiny.synth.voice_mix"] = maxabs(out["mel"], oo["mel"])
+    rec["mel_mix"] = out["mel"].numpy()
+    np.savez(HERE / "tiny_synth.npz", **rec)
+
+    def ref_batched(model, x, x_len, spk, steps, sc=1.0, ls=1.0):
+        """reference components composed exactly as inference.py:124-172 does, with [B,S] speaker embeddings."""
+        e_enc = model.speaker_embeddings_enc(spk)
+        e_dur = model.speaker_embeddings_dur(spk)
+        mu_x, logw, x_mask = model.encoder(x, x_len, e_enc, e_dur)
+        d = ((torch.exp(logw) - 2) * x_mask).squeeze(1) * sc * ls
+        d = d.round().clamp(min=1) * x_mask.squeeze(1)
+        yfl = torch.clamp_min(d.sum(dim=1).long(), 1)
+        tf = fix_len_compatibility(yfl.max()) * 2
+        yfm = sequence_mask(yfl, tf).unsqueeze(1).to(x_mask.dtype)
+        am = x_mask.unsqueeze(-1) * yfm.unsqueeze(2)
+        attn = generate_path(d, am.squeeze(1)).unsqueeze(1)
+        mu_y = downsample(torch.matmul(mu_x.float(), attn.float().squeeze(1)))
+        yl = torch.clamp_min((yfl + 1) // 2, 1)
+        ym = sequence_mask(yl, tf // 2).unsqueeze(1).to(x_mask.dtype)
+        dec = model.decoder(mu_y, ym, steps)[:, :, : int(yl.max())]
+        return dict(mel=denormalize(dec, model.mel_mean, model.mel_std), logw=logw, mu_y=mu_y, y_lengths=yl, mu_x=mu_x)
+
+    # ------------------------------------------------------------------ prod shapes, single utterance
+    hp = hparams.prod_v20(n_spks=1)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    model = build_ref_model(ref_inf, hp, sd)
+    n_params = sum(p.numel() for p in model.parameters())
+    report["prod.n_params(n_spks=1)"] = n_params
+    x, x_len, spk = synthetic.make_inputs(hp, 1, 128, seed=1234)
+    rec = {"x": x.numpy()}
+    for solver, steps in (("euler", 2), ("euler", 10), ("midpoint", 4)):
+        model.decoder.solver = solver
+        out = model.synthesise(x, x_len, n_timesteps=steps, speaker=0, debug=True)
+        oo = O.synthesise(sd, hp, x, x_len, steps, speaker=0, solver=solver)
+        report[f"prod.synth.{solver}{steps}"] = maxabs(out["mel"], oo["mel"])
+        rec[f"mel_{solver}{steps}"] = out["mel"].numpy()
+    rb = ref_batched(model, x, x_len, spk, 1)
+    rec["logw"] = rb["logw"].numpy()
+    rec["mu_y"] = rb["mu_y"].numpy()
+    # one decoder evaluation at t = 0.5 on (z, mu_y)
+    z = synthetic.cpu_noise(rb["mu_y"].shape)
+    ym = sequence_mask(rb["y_lengths"], rb["mu_y"].shape[-1]).unsqueeze(1).float()
+    v = model.decoder.estimator(rb["mu_y"] + z, ym, rb["mu_y"], torch.tensor(0.5))
+    ov = O.decoder_forward(sd, hp, rb["mu_y"] + z, ym, rb["mu_y"], torch.tensor(0.5))
+    report["prod.decoder.1nfe"] = maxabs(v, ov)
+    rec["v_t0.5"] = v.numpy()
+    np.savez(HERE / "prod_synth.npz", **rec)
+
+    # ------------------------------------------------------------------ prod shapes, ragged batch
+    hp3 = hparams.prod_v20(n_spks=3)
+    sd3 = synthetic.make_state_dict(hp3, seed=7)
+    model3 = build_ref_model(ref_inf, hp3, sd3)
+    x, x_len, spk = synthetic.make_inputs(hp3, 3, 128, seed=1234, lengths=[128, 100, 77])
+    model3.decoder.solver = "euler"
+    rb = ref_batched(model3, x, x_len, spk, 2)
+    oo = O.synthesise(sd3, hp3, x, x_len, 2, speaker=spk, solver="euler")
+    report["prod.batch3.euler2"] = maxabs(rb["mel"], oo["mel"])
+    np.savez(HERE / "prod_batch.npz", x=x.numpy(), x_lengths=x_len.numpy(), speakers=spk.numpy(),
+             mel=rb["mel"].numpy(), y_lengths=rb["y_lengths"].numpy())
+
+    np.savez(HERE / "randn42.npz", head=synthetic.cpu_noise((1, 100, 640)).flatten()[:16].numpy(),
+             tail=synthetic.cpu_noise((1, 100, 640)).flatten()[-16:].numpy())
+
+    print("oracle vs reference, max-abs:")
+    for k, v in report.items():
+        print(f"  {k:32s} {v:.3e}" if isinstance(v, float) else f"  {k:32s} {v}")
+    worst = max(v for v in report.values() if isinstance(v, float))
+    print("worst:", worst)
+    (HERE / "REPORT.txt").write_text("\n".join(f"{k} {v}" for k, v in report.items()) + "\n")
+
+
+if __name__ == "__main__":
+    main()
