@@ -1,0 +1,165 @@
+/*
+ * mtts.h -- C ABI of libmtts_hip.so: the MI355X (gfx950) implementation of the mel-synthesis
+ * hot path of faltiska/Matcha-TTS-24k.
+ *
+ * The reference has no native code and no FFI on this path: its boundary is the Python module
+ * matcha/inference.py.  This header is what a Python (ctypes) or C++ host
+ * binds instead of calling PyTorch ops; each entry point cites the reference function it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (fp32 unless stated); h_* is a HOST pointer
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream)
+ *   - functions return 0 on success, <0 on error; mtts_last_error() gives a thread-local message
+ *   - launch functions never allocate, never synchronise and never touch the default stream:
+ *     scratch memory is a caller-provided workspace sized by the matching *_workspace_bytes()
+ *   - tensors use the reference's layouts at the boundary: activations [B, C, T] ("channels first"),
+ *     ids/lengths int64
+ */
+#ifndef MTTS_H
+#define MTTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTTS_ABI_VERSION 1
+
+typedef struct mtts_ctx mtts_ctx;
+
+/* Architecture of the path; mirrors the checkpoint's hyper_parameters
+ * (reference matcha/inference.py:45-55, configs/experiment/v20.yaml:17-63). */
+typedef struct mtts_config {
+    int32_t n_feats;        /* mel bins (100) */
+    int32_t n_spks;
+    int32_t spk_emb_dim;    /* 96 */
+    int32_t n_vocab;        /* 600 */
+    /* text encoder, reference text_encoder.py:319-373 */
+    int32_t enc_channels;   /* 192; hidden = enc_channels + spk_emb_dim */
+    int32_t enc_filter;     /* 1152 */
+    int32_t enc_heads;      /* 6 */
+    int32_t enc_layers;     /* 4 */
+    int32_t enc_kernel;     /* 5 */
+    int32_t prenet_layers;  /* 6 */
+    int32_t prenet_kernel;  /* 3 */
+    int32_t dp_filter;      /* 96 */
+    int32_t dp_kernel;      /* 5 */
+    int32_t dp_layers;      /* 4 */
+    /* decoder, reference decoder.py:202-310 */
+    int32_t dec_levels;     /* len(channels) == 2 */
+    int32_t dec_channels[4];
+    int32_t dec_head_dim;   /* 64 */
+    int32_t dec_heads;      /* 6 */
+    int32_t dec_n_blocks;   /* 2 */
+    int32_t dec_mid_blocks; /* 2 */
+} mtts_config;
+
+enum { MTTS_SOLVER_EULER = 0, MTTS_SOLVER_MIDPOINT = 1, MTTS_SOLVER_RK4 = 2 };
+
+/* ---------------------------------------------------------------- library / context */
+int mtts_abi_version(void);
+const char* mtts_last_error(void);
+
+/* Create a context for one architecture.  Host-side only (no device work). */
+mtts_ctx* mtts_create(const mtts_config* cfg);
+void mtts_destroy(mtts_ctx* ctx);
+
+/* Register one tensor of the reference state dict by its key, e.g.
+ * "decoder.estimator.down_blocks.0.0.block1.block.0.weight".  h_data: host fp32, copied.
+ * Replaces nn.Module.load_state_dict (reference inference.py:186-197). */
+int mtts_set_tensor(mtts_ctx* ctx, const char* key, const float* h_data, int64_t numel);
+
+/* After all tensors are registered: size of the packed device image, then pack + upload it
+ * (GEMM-ready [N][K] panels, conv taps unrolled along K, LayerNorm affine folded into the
+ * following projection, exp() of the SnakeBeta parameters).  Synchronous; load time only. */
+int64_t mtts_weights_bytes(mtts_ctx* ctx);
+int mtts_upload_weights(mtts_ctx* ctx, void* d_weights, int64_t bytes);
+
+/* ---------------------------------------------------------------- the path */
+
+/* TextEncoder.forward -- reference matcha/models/components/text_encoder.py:375-406.
+ * d_x [B,Tx] int64, d_x_lengths [B] int64, d_e_enc/d_e_dur [B,spk_emb_dim].
+ * Outputs: d_mu_x [B,n_feats,Tx], d_logw [B,1,Tx], d_x_mask [B,1,Tx] (float 0/1). */
+int64_t mtts_encoder_workspace_bytes(mtts_ctx* ctx, int B, int Tx);
+int mtts_text_encoder_forward(mtts_ctx* ctx, const int64_t* d_x, const int64_t* d_x_lengths, const float* d_e_enc,
+                              const float* d_e_dur, int B, int Tx, float* d_mu_x, float* d_logw, float* d_x_mask,
+                              void* d_ws, int64_t ws_bytes, void* stream);
+
+/* Speaker table lookup -- reference inference.py:115-121 (table: 0 = enc, 1 = dur); d_ids [B] int64. */
+int mtts_speaker_embedding(mtts_ctx* ctx, int table, const int64_t* d_ids, int B, float* d_out, void* stream);
+
+/* Durations -- reference inference.py:127-146:
+ * round((exp(logw)-2)*mask*scale_correction*length_scale).clamp(min=1)*mask, their inclusive cumulative sum and the
+ * per-utterance fine length clamp_min(sum,1).
+ * d_durations [B,Tx] f32, d_cum [B,Tx] int32, d_y_fine_lengths [B] int64. */
+int mtts_durations(const float* d_logw, const float* d_x_mask, float scale_correction, float length_scale, int B, int Tx,
+                   float* d_durations, int32_t* d_cum, int64_t* d_y_fine_lengths, void* stream);
+
+/* generate_path + matmul + downsample + sequence_mask -- reference inference.py:146-167,
+ * utils/model.py:7-9,24-40,57-68.  T_pad = fix_len_compatibility(max fine length) (host decides it).
+ * Outputs: d_mu_y [B,n_feats,T_pad], d_y_mask [B,1,T_pad], d_y_lengths [B] int64. */
+int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_y_fine_lengths, int B, int n_feats,
+                    int Tx, int T_pad, float* d_mu_y, float* d_y_mask, int64_t* d_y_lengths, void* stream);
+
+/* Decoder.forward -- reference matcha/models/components/decoder.py:359-426 (one evaluation of the velocity field).
+ * d_x, d_mu, d_out [B,n_feats,T]; d_mask [B,1,T]; t scalar. */
+int64_t mtts_decoder_workspace_bytes(mtts_ctx* ctx, int B, int T);
+int mtts_decoder_forward(mtts_ctx* ctx, const float* d_x, const float* d_mask, const float* d_mu, float t, int B, int T,
+                         float* d_out, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* BASECFM.solve -- reference matcha/models/components/flow_matching.py:60-63 + torchdiffeq fixed-grid odeint
+ * (euler / midpoint / rk4 = 3/8 rule) over the grid h_t_span[0..n_steps].
+ * d_x0 [B,n_feats,T] initial state; if add_mu != 0 the state starts at d_x0 + d_mu (use_mu_prior,
+ * flow_matching.py:52-55).  d_out [B,n_feats,T_out] receives state[:, :, :T_out]*out_scale + out_shift
+ * (the slice and denormalize of reference inference.py:170-172; pass T_out=T, 1, 0 for the raw state). */
+int mtts_cfm_solve(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const float* d_mask, int add_mu,
+                   const float* h_t_span, int n_steps, int solver, int B, int T, float* d_out, int T_out,
+                   float out_scale, float out_shift, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- single kernels (parity tests, building blocks) */
+
+/* C[M,N] = epilogue(prologue(A)[M,K] * W[N,K]^T): the fp32-MFMA GEMM every Linear/Conv1d of the path runs on.
+ * A is [B*T_in, lda] row major (channels last).  ntaps>1 makes it an implicit 1-D convolution:
+ * K = ntaps*C, output row (b,t) reads input rows t*in_stride + tap_off[tap].  W is the *unpacked* torch weight:
+ * Linear [N,C] or Conv1d [N,C,ntaps]; it is packed into d_wpacked (mtts_gemm_packed_bytes) on the stream first.
+ * act: 0 none, 1 relu, 2 silu, 3 SnakeBeta with d_p0 = exp(alpha)[N], d_p1 = 1/(exp(beta)+1e-9)[N]
+ * (reference transformer.py:61-77).  Epilogue: c = act(acc + bias); c *= out_mask[row]; c = c*out_scale + res[row][n].
+ * All optional pointers may be NULL. */
+int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps);
+int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride,
+                  int T_out, const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_w,
+                  void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
+                  const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc,
+                  void* stream);
+
+/* Self-attention over packed [B*T, 3*H*D] q|k|v rows -> [B*T, H*D].  mask_mode 0: additive float key bias
+ * (diffusers semantics, reference transformer.py:253-258); 1: boolean query*key mask (reference
+ * text_encoder.py:228-235,306).  d_mask [B,T] float 0/1. */
+int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode,
+                       float* d_out, void* stream);
+
+/* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
+int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);
+
+/* Block1D tail -- reference decoder.py:38-45: Mish(GroupNorm_G(y)) * mask over y [B,T,C] (channels last);
+ * statistics over (C/G channels x all T frames).  d_scratch: mtts_groupnorm_scratch_bytes. */
+int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G);
+int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_beta, const float* d_mask, int B, int T,
+                        int C, int G, float eps, float* d_out, void* d_scratch, void* stream);
+
+/* ---------------------------------------------------------------- measurement */
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline line).
+ * Classes: 0 gemm, 1 attention, 2 norm/activation/elementwise. */
+int mtts_prof_enable(mtts_ctx* ctx, int on);
+int mtts_prof_reset(mtts_ctx* ctx);
+/* Synchronises the recorded events; returns launches, summed milliseconds and algorithmic FLOPs of a class. */
+int mtts_prof_read(mtts_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTTS_H */

@@ -1,0 +1,344 @@
+"""ctypes binding of libmtts_hip.so (C ABI in include/mtts.h) + the in-tree hipcc build.
+
+There is no CPU fallback: every entry point raises if the library is missing or a tensor is not
+on a HIP device.  PyTorch is used only for device memory (workspaces, outputs) and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .hparams import PathHParams
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libmtts_hip.so"
+SOURCES = ["gemm_f32.hip", "attention_f32.hip", "norm_glue.hip", "model.hip"]
+HEADERS = [CSRC / "kernels.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
+SOLVERS = {"euler": 0, "midpoint": 1, "rk4": 2}
+
+
+class MttsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_feats", "n_spks", "spk_emb_dim", "n_vocab", "enc_channels", "enc_filter", "enc_heads", "enc_layers",
+        "enc_kernel", "prenet_layers", "prenet_kernel", "dp_filter", "dp_kernel", "dp_layers", "dec_levels")] + [
+        ("dec_channels", C.c_int32 * 4)] + [(n, C.c_int32) for n in (
+            "dec_head_dim", "dec_heads", "dec_n_blocks", "dec_mid_blocks")]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into libmtts_hip.so next to this file (cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    if LIB.exists() and not force:
+        newest = max(p.stat().st_mtime for p in srcs + HEADERS)
+        if LIB.stat().st_mtime >= newest:
+            return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           *[str(s) for s in srcs], "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    return LIB
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and declare every signature of include/mtts.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB.exists():
+        raise RuntimeError(f"{LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP path has no CPU fallback)")
+    lib = C.CDLL(str(LIB))
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        "mtts_abi_version": (i32, []),
+        "mtts_last_error": (C.c_char_p, []),
+        "mtts_create": (vp, [C.POINTER(MttsConfig)]),
+        "mtts_destroy": (None, [vp]),
+        "mtts_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
+        "mtts_weights_bytes": (i64, [vp]),
+        "mtts_upload_weights": (i32, [vp, vp, i64]),
+        "mtts_encoder_workspace_bytes": (i64, [vp, i32, i32]),
+        "mtts_text_encoder_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+        "mtts_speaker_embedding": (i32, [vp, i32, vp, i32, vp, vp]),
+        "mtts_durations": (i32, [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp]),
+        "mtts_align_pool": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "mtts_decoder_workspace_bytes": (i64, [vp, i32, i32]),
+        "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
+        "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
+        "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
+        "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp,
+                                i32, vp, f32, vp, i32, vp]),
+        "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
+        "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
+        "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
+        "mtts_groupnorm_mish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+        "mtts_prof_enable": (i32, [vp, i32]),
+        "mtts_prof_reset": (i32, [vp]),
+        "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mtts_abi_version() != 1:
+        raise RuntimeError("libmtts_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("mtts: " + load().mtts_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous HIP tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mtts: tensor is not on a HIP device; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("mtts: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rope_tables(d: int, n: int = 4000):
+    """cos/sin caches exactly as the reference builds them (text_encoder.py:138-146), [n, d] fp32 on the CPU."""
+    theta = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    idx = torch.einsum("n,d->nd", torch.arange(n).float(), theta)
+    idx2 = torch.cat([idx, idx], dim=1)
+    return idx2.cos().contiguous(), idx2.sin().contiguous()
+
+
+def time_freqs(dim: int) -> torch.Tensor:
+    """Frequency table of SinusoidalPosEmb in the reference's fp32 arithmetic (decoder.py:24-26)."""
+    import math
+    half = dim // 2
+    c = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half).float() * -c).contiguous()
+
+
+class HipModel:
+    """One mtts_ctx: packed weights on a device + cached workspaces + the path's entry points on torch tensors."""
+
+    def __init__(self, hp: PathHParams):
+        self.lib = load()
+        self.hp = hp
+        cfg = MttsConfig()
+        e, d = hp.encoder, hp.decoder
+        cfg.n_feats, cfg.n_spks, cfg.spk_emb_dim, cfg.n_vocab = hp.n_feats, hp.n_spks, hp.spk_emb_dim, hp.n_vocab
+        cfg.enc_channels, cfg.enc_filter, cfg.enc_heads, cfg.enc_layers = e.n_channels, e.filter_channels, e.n_heads, e.n_layers
+        cfg.enc_kernel, cfg.prenet_layers, cfg.prenet_kernel = e.kernel_size, e.prenet_layers, e.prenet_kernel_size
+        cfg.dp_filter, cfg.dp_kernel, cfg.dp_layers = e.dp_filter_channels, e.dp_kernel_size, e.dp_n_layers
+        if len(d.channels) > 4:
+            raise ValueError("at most 4 decoder levels")
+        cfg.dec_levels = len(d.channels)
+        for i, ch in enumerate(d.channels):
+            cfg.dec_channels[i] = ch
+        cfg.dec_head_dim, cfg.dec_heads, cfg.dec_n_blocks, cfg.dec_mid_blocks = (d.attention_head_dim, d.num_heads, d.n_blocks,
+                                                                                d.num_mid_blocks)
+        self.ctx = self.lib.mtts_create(C.byref(cfg))
+        if not self.ctx:
+            raise RuntimeError("mtts_create: " + self.lib.mtts_last_error().decode())
+        self.weights: Optional[torch.Tensor] = None
+        self.device: Optional[torch.device] = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.mtts_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _set(self, key: str, t: torch.Tensor) -> None:
+        a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+        check(self.lib.mtts_set_tensor(self.ctx, key.encode(), a.ctypes.data, a.size))
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], device) -> None:
+        """Register every tensor of a reference-format state dict (keys of SURVEY appendix A; torch.compile's
+        ``_orig_mod.`` infix is ignored), add the host-precomputed tables, pack and upload."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("mtts: weights must live on a HIP device; the HIP path has no CPU fallback")
+        for k, v in sd.items():
+            k = k.replace("_orig_mod.", "")
+            if k in ("mel_mean", "mel_std") or "rope." in k:
+                continue
+            self._set(k, v)
+            if k.endswith("ff.net.0.alpha"):     # SnakeBeta parameters in the reference's own fp32 ops (transformer.py:68-75)
+                self._set(k + "_exp", torch.exp(v.detach().float().cpu()))
+            elif k.endswith("ff.net.0.beta"):
+                self._set(k[:-4] + "inv_beta", 1.0 / (torch.exp(v.detach().float().cpu()) + 0.000000001))
+        e = self.hp.encoder
+        dh = (e.n_channels + self.hp.spk_emb_dim) // e.n_heads
+        cos, sin = rope_tables(int(dh * 0.5))
+        self._set("aux.rope_cos", cos)
+        self._set("aux.rope_sin", sin)
+        self._set("aux.time_freqs", time_freqs(2 * self.hp.n_feats))
+        nbytes = self.lib.mtts_weights_bytes(self.ctx)
+        if nbytes < 0:
+            check(-1)
+        self.weights = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(self.lib.mtts_upload_weights(self.ctx, self.weights.data_ptr(), nbytes))
+        self.device = device
+        self._ws.clear()
+
+    def _workspace(self, kind: str, a: int, b: int) -> torch.Tensor:
+        key = (kind, a, b)
+        ws = self._ws.get(key)
+        if ws is None:
+            fn = self.lib.mtts_decoder_workspace_bytes if kind == "dec" else self.lib.mtts_encoder_workspace_bytes
+            n = fn(self.ctx, a, b)
+            if n < 0:
+                check(-1)
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        if not t.is_cuda:
+            raise RuntimeError("mtts: input tensor is not on a HIP device; the HIP path has no CPU fallback")
+        return t.detach().to(torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ the path
+    def text_encoder(self, x, x_lengths, e_enc, e_dur):
+        B, Tx = x.shape
+        x = x.detach().to(torch.int64).contiguous()
+        x_lengths = x_lengths.detach().to(torch.int64).contiguous()
+        e_enc, e_dur = self._f32(e_enc), self._f32(e_dur)
+        if e_enc.shape[0] != B:
+            e_enc, e_dur = e_enc.expand(B, -1).contiguous(), e_dur.expand(B, -1).contiguous()
+        nf = self.hp.n_feats
+        mu_x = torch.empty(B, nf, Tx, dtype=torch.float32, device=x.device)
+        logw = torch.empty(B, 1, Tx, dtype=torch.float32, device=x.device)
+        x_mask = torch.empty(B, 1, Tx, dtype=torch.float32, device=x.device)
+        ws = self._workspace("enc", B, Tx)
+        check(self.lib.mtts_text_encoder_forward(self.ctx, ptr(x), ptr(x_lengths), ptr(e_enc), ptr(e_dur), B, Tx, ptr(mu_x),
+                                                 ptr(logw), ptr(x_mask), ws.data_ptr(), ws.numel(), stream_ptr()))
+        return mu_x, logw, x_mask
+
+    def speaker_embedding(self, table: int, ids: torch.Tensor) -> torch.Tensor:
+        ids = ids.detach().to(torch.int64).contiguous()
+        out = torch.empty(ids.numel(), self.hp.spk_emb_dim, dtype=torch.float32, device=ids.device)
+        check(self.lib.mtts_speaker_embedding(self.ctx, table, ptr(ids), ids.numel(), ptr(out), stream_ptr()))
+        return out
+
+    def durations(self, logw, x_mask, scale_correction: float, length_scale: float):
+        logw, x_mask = self._f32(logw), self._f32(x_mask)
+        B, _, Tx = logw.shape
+        dur = torch.empty(B, Tx, dtype=torch.float32, device=logw.device)
+        cum = torch.empty(B, Tx, dtype=torch.int32, device=logw.device)
+        yfl = torch.empty(B, dtype=torch.int64, device=logw.device)
+        check(self.lib.mtts_durations(ptr(logw), ptr(x_mask), float(scale_correction), float(length_scale), B, Tx, ptr(dur),
+                                      ptr(cum), ptr(yfl), stream_ptr()))
+        return dur, cum, yfl
+
+    def align_pool(self, mu_x, cum, y_fine_lengths, t_pad: int):
+        mu_x = self._f32(mu_x)
+        B, nf, Tx = mu_x.shape
+        mu_y = torch.empty(B, nf, t_pad, dtype=torch.float32, device=mu_x.device)
+        y_mask = torch.empty(B, 1, t_pad, dtype=torch.float32, device=mu_x.device)
+        y_len = torch.empty(B, dtype=torch.int64, device=mu_x.device)
+        check(self.lib.mtts_align_pool(ptr(mu_x), ptr(cum), ptr(y_fine_lengths), B, nf, Tx, t_pad, ptr(mu_y), ptr(y_mask),
+                                       ptr(y_len), stream_ptr()))
+        return mu_y, y_mask, y_len
+
+    def decoder_forward(self, x, mask, mu, t: float):
+        x, mask, mu = self._f32(x), self._f32(mask), self._f32(mu)
+        B, nf, T = x.shape
+        out = torch.empty_like(x)
+        ws = self._workspace("dec", B, T)
+        check(self.lib.mtts_decoder_forward(self.ctx, ptr(x), ptr(mask), ptr(mu), float(t), B, T, ptr(out), ws.data_ptr(),
+                                            ws.numel(), stream_ptr()))
+        return out
+
+    def cfm_solve(self, x0, mu, mask, t_span, solver: str, add_mu: bool = False, t_out: Optional[int] = None,
+                  out_scale: float = 1.0, out_shift: float = 0.0):
+        x0, mu, mask = self._f32(x0), self._f32(mu), self._f32(mask)
+        B, nf, T = x0.shape
+        if solver not in SOLVERS:
+            raise ValueError(f"unsupported solver {solver!r} (euler, midpoint, rk4)")
+        ts = np.ascontiguousarray(torch.as_tensor(t_span).detach().to("cpu", torch.float32).numpy())
+        t_out = T if t_out is None else int(t_out)
+        out = torch.empty(B, nf, t_out, dtype=torch.float32, device=x0.device)
+        ws = self._workspace("dec", B, T)
+        check(self.lib.mtts_cfm_solve(self.ctx, ptr(x0), ptr(mu), ptr(mask), int(bool(add_mu)), ts.ctypes.data, len(ts) - 1,
+                                      SOLVERS[solver], B, T, ptr(out), t_out, float(out_scale), float(out_shift),
+                                      ws.data_ptr(), ws.numel(), stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ measurement
+    def prof_enable(self, on: bool) -> None:
+        check(self.lib.mtts_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self) -> None:
+        check(self.lib.mtts_prof_reset(self.ctx))
+
+    def prof_read(self, klass: int):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        check(self.lib.mtts_prof_read(self.ctx, klass, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+
+# ---------------------------------------------------------------------- single kernels (used by the parity tests)
+def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1, a_mask=None, a_mean=None, a_rstd=None,
+             act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0):
+    """a [B*T_in, C]; w Linear [N, C] or Conv1d [N, C, k]."""
+    lib = load()
+    N, Cc = w.shape[0], w.shape[1]
+    ntaps = w.shape[2] if w.dim() == 3 else 1
+    T_out = T_in if T_out is None else T_out
+    taps = (C.c_int * ntaps)(*(tap_off if tap_off is not None else [j - ntaps // 2 for j in range(ntaps)]))
+    packed = torch.empty(lib.mtts_gemm_packed_bytes(N, Cc, ntaps), dtype=torch.uint8, device=a.device)
+    out = torch.empty(B * T_out, N, dtype=torch.float32, device=a.device)
+    check(lib.mtts_gemm_f32(ptr(a), a.shape[1], B, T_in, Cc, ntaps, taps, in_stride, T_out, ptr(a_mask), ptr(a_mean), ptr(a_rstd),
+                            ptr(w.contiguous()), packed.data_ptr(), ptr(bias), N, act, ptr(p0), ptr(p1), ptr(res),
+                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, stream_ptr()))
+    return out
+
+
+def attention_f32(qkv, mask, B, T, H, D, scale, mask_mode):
+    lib = load()
+    out = torch.empty(B * T, H * D, dtype=torch.float32, device=qkv.device)
+    check(lib.mtts_attention_f32(ptr(qkv), ptr(mask), B, T, H, D, float(scale), mask_mode, ptr(out), stream_ptr()))
+    return out
+
+
+def row_stats(x, eps=1e-5):
+    lib = load()
+    M, Cc = x.shape
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib.mtts_row_stats(ptr(x), M, Cc, Cc, eps, ptr(mean), ptr(rstd), stream_ptr()))
+    return mean, rstd
+
+
+def groupnorm_mish(y, gamma, beta, mask, B, T, G=8, eps=1e-5):
+    lib = load()
+    Cc = y.shape[1]
+    scratch = torch.empty(lib.mtts_groupnorm_scratch_bytes(B, T, G), dtype=torch.uint8, device=y.device)
+    out = torch.empty_like(y)
+    check(lib.mtts_groupnorm_mish(ptr(y), ptr(gamma), ptr(beta), ptr(mask), B, T, Cc, G, eps, ptr(out), scratch.data_ptr(),
+                                  stream_ptr()))
+    return out

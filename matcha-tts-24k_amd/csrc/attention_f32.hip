@@ -1,0 +1,198 @@
+// fp32 flash-style self-attention for gfx950 (CDNA4): one pass over the keys, online softmax, no T x T buffer.
+//
+// Replaces, on packed q|k|v rows [B*T, 3*H*D]:
+//   decoder: diffusers Attention via BasicTransformerBlock (reference transformer.py:249-261; decoder.py:379-385):
+//            softmax(q k^T / sqrt(D) + bias) v with an ADDITIVE float key bias (mask value 1.0 valid / 0.0 padded)
+//   encoder: F.scaled_dot_product_attention with a boolean query*key mask (reference text_encoder.py:228-235,306)
+//
+// Work split: grid (ceil(T/128), H, B); a 256-thread workgroup owns 128 queries of one (batch, head), each of its
+// 4 waves 32 of them.  Keys/values stream through LDS in tiles of 64 (global -> registers prefetch -> LDS).
+// Both products run on v_mfma_f32_32x32x2_f32 in the "transposed" orientation so that the query sits on the lane:
+//   S^T[key][q] = K[key][:] . Q[q][:]     A = K fragment (LDS, ds_read_b128), B = Q fragment (registers, loaded once)
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]   A = V column (LDS, ds_read_b32), B = the S^T accumulator itself
+// so the softmax row (max, sum) is a reduction over the lane's own registers plus one cross-half shuffle, the
+// probabilities never leave registers, and the per-query rescale is a lane-uniform multiply of the O^T accumulators.
+// Head dims below 64 (encoder: 48) are zero-padded to 64 in the staged tiles.
+#include "kernels.h"
+
+namespace mtts {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int AT_Q = 128;     // queries per workgroup
+constexpr int AT_K = 64;      // keys per tile
+constexpr int AT_D = 64;      // padded head dim
+constexpr int AT_S = 68;      // LDS row stride (floats): 17 x 16 B, conflict-free b128 row reads
+constexpr float NEG_BIG = -1e30f;
+
+__global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_K * AT_S];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_K * AT_S];
+    __shared__ __attribute__((aligned(16))) float Bs[AT_K];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * AT_Q + wave * 32;
+    const int ld = 3 * p.H * p.D;
+    const size_t rowbase = (size_t)b * p.T;
+    const float* qptr = p.qkv + head * p.D;
+    const float* kptr = p.qkv + p.H * p.D + head * p.D;
+    const float* vptr = p.qkv + 2 * p.H * p.D + head * p.D;
+    const float ninf = -__builtin_huge_valf();
+
+    // ---- Q fragment: lane (q = lq, half h) holds Q[q][8g + 4h + kk] * scale, g < 8, kk < 4
+    const int qi = q0 + lq;
+    const bool q_in = qi < p.T;
+    bool q_ok = q_in;
+    if (p.mask_mode == 1 && q_in) q_ok = p.mask[rowbase + qi] != 0.f;
+    f32x4 qf[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int d = 8 * g + 4 * h;
+        if (q_in && d < p.D) v = *reinterpret_cast<const f32x4*>(qptr + (rowbase + qi) * ld + d);
+        qf[g] = v * p.scale;
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // ---- staging: thread -> key row tid>>2, float4 columns (tid&3)*4 + 16c: 4 lanes read 64 contiguous bytes per load
+    const int srow = tid >> 2;           // 0..63
+    const int sd = (tid & 3) * 4;
+    f32x4 rk[4], rv[4];
+    float rbias = 0.f;
+    auto fetch = [&](int k0) {
+        const int key = k0 + srow;
+        const bool in = key < p.T;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            const int d = sd + 16 * c;
+            if (in && d < p.D) {
+                kv = *reinterpret_cast<const f32x4*>(kptr + (rowbase + key) * ld + d);
+                vv = *reinterpret_cast<const f32x4*>(vptr + (rowbase + key) * ld + d);
+            }
+            rk[c] = kv;
+            rv[c] = vv;
+        }
+        if ((tid & 3) == 0) {
+            float bv = ninf;
+            if (in) {
+                const float mv = p.mask ? p.mask[rowbase + key] : 1.0f;
+                bv = (p.mask_mode == 0) ? mv : (mv != 0.f ? 0.f : ninf);
+            }
+            rbias = bv;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<f32x4*>(Ks + srow * AT_S + sd + 16 * c) = rk[c];
+            *reinterpret_cast<f32x4*>(Vs + srow * AT_S + sd + 16 * c) = rv[c];
+        }
+        if ((tid & 3) == 0) Bs[srow] = rbias;
+    };
+
+    const int ntiles = (p.T + AT_K - 1) / AT_K;
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt) __syncthreads();          // everyone finished reading the previous tile
+        stage();
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch((kt + 1) * AT_K);
+
+        // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const float* kp = Ks + (32 * t + lq) * AT_S + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * g);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kk], qf[g][kk], s[t], 0, 0, 0);
+            }
+        }
+        // ---- bias + online softmax.  Register r of sub-tile t is key 32t + (r&3) + 8(r>>2) + 4h.
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + 32 * t + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = q_ok ? s[t][4 * g4 + e] + bb[e] : ninf;
+                    s[t][4 * g4 + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = expf(s[t][r] - m_new);
+                s[t][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v0 = Vs[key * AT_S + lq];
+                const float v1 = Vs[key * AT_S + 32 + lq];
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[t][r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[t][r], o[1], 0, 0, 0);
+            }
+    }
+
+    // ---- normalise and store: lane holds query qi; register r of d-tile t is d = 32t + (r&3) + 8(r>>2) + 4h
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_in) {
+        float* op = p.out + (rowbase + qi) * (size_t)(p.H * p.D) + head * p.D;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * t + 8 * g4 + 4 * h;
+                if (d < p.D) {
+                    f32x4 v = {o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv, o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv};
+                    *reinterpret_cast<f32x4*>(op + d) = v;
+                }
+            }
+    }
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (!a.qkv || !a.out || a.B <= 0 || a.T <= 0 || a.H <= 0) return hipErrorInvalidValue;
+    if (a.D <= 0 || a.D > AT_D || (a.D & 3)) return hipErrorInvalidValue;
+    if (a.mask_mode == 1 && !a.mask) return hipErrorInvalidValue;
+    dim3 grid((a.T + AT_Q - 1) / AT_Q, a.H, a.B);
+    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mtts

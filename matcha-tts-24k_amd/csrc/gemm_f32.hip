@@ -1,0 +1,291 @@
+// fp32 MFMA GEMM / implicit 1-D convolution for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T )        M = B*T_out rows of channels-last activations
+//
+// Every Linear and Conv1d/ConvTranspose1d of the reference path runs on this one kernel:
+//   Linear                  reference transformer.py:104-120,249-261 (to_q/k/v, to_out, FeedForward)
+//   Conv1d k3 / k5 / 1x1    reference decoder.py:32-72,252-254,301-310; text_encoder.py:30-62,101-112,210-258
+//   ConvTranspose1d k4 s2   reference decoder.py:146 (two phase-GEMMs of two taps each)
+// A convolution is a GEMM whose K axis is (tap, channel): the A tile of tap j is the same activation matrix read at
+// rows shifted by tap_off[j] (zero outside [0,T_in)), so no im2col buffer exists.  Channel concatenation
+// (pack([x, mu]) decoder.py:371, skip connections decoder.py:410) is two K segments read from two tensors.
+//
+// Tiling (one 256-thread workgroup = 4 waves, 2x2):
+//   block tile 128x128x32, wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs)
+//   global -> registers (prefetch of tile k+1 issued before the MFMAs of tile k) -> LDS, two LDS buffers, one barrier per k-step
+//   LDS rows are K-contiguous, stride 36 floats: the 16-byte fragment reads (ds_read_b128) and tile writes are conflict free
+//   inside a group of 8 k the MFMA kk consumes k = {kk, 4+kk}: lane half h owns k = 4h..4h+3, i.e. one ds_read_b128
+//   feeds four MFMAs per operand (the k permutation is the same for A and W, so the sum is unchanged)
+// fp32-input MFMA is an exact fp32 FMA chain (157 TFLOP/s peak): results differ from a CPU GEMM only by summation order.
+#include "kernels.h"
+
+namespace mtts {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int LDS_STRIDE = GEMM_BK + 4;                              // 36 floats = 144 B (9 x 16 B)
+constexpr int TILE_FLOATS = (GEMM_BM + GEMM_BN) * LDS_STRIDE;        // one (A,B) stage
+constexpr int GEMM_LDS_BYTES = 2 * TILE_FLOATS * 4;                  // 73,728 B -> 2 workgroups per CU
+
+__device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
+    switch (act) {
+        case ACT_RELU: return c > 0.f ? c : 0.f;
+        case ACT_SILU: return c / (1.0f + expf(-c));
+        case ACT_SNAKE: {   // reference transformer.py:75: x + 1/(beta+1e-9) * sin(x*alpha)^2
+            float s = sinf(c * p0);
+            return c + p1 * (s * s);
+        }
+        default: return c;
+    }
+}
+
+template <bool A_MASK, bool A_NORM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.B * p.T_out;
+    const int Kp = p.ntaps * p.ktap;
+    const int n_tiles = (p.N + GEMM_BN - 1) / GEMM_BN;
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
+    // tiles (the N-tiles of one M-tile share their A rows in that XCD's L2).  Bijective for any grid size.
+    int swz;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int m0 = (swz / n_tiles) * GEMM_BM;
+    const int n0 = (swz % n_tiles) * GEMM_BN;
+
+    // ---- per-thread staging coordinates: 4 rows x one float4 of K for A and for W
+    const int lrow = tid >> 3;
+    const int lq = (tid & 7) * 4;
+    int arow_base[4], at[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < M) {
+            const int b = m / p.T_out;
+            arow_base[i] = b * p.T_in;
+            at[i] = (m - b * p.T_out) * p.in_stride;
+        } else {
+            arow_base[i] = 0;
+            at[i] = -(1 << 28);
+        }
+    }
+    const float* wrow = p.w + (size_t)(n0 + lrow) * Kp + lq;
+
+    f32x4 ra[4], rb[4];
+    int ld_tap = 0, ld_c = 0;   // (tap, channel) of the next tile to fetch
+    auto fetch = [&]() {
+        const int c = ld_c + lq;
+        const float* src;
+        int ld, cc;
+        bool cvalid;
+        if (c < p.c0) { src = p.a0; ld = p.lda0; cc = c; cvalid = true; }
+        else { src = p.a1; ld = p.lda1; cc = c - p.c0; cvalid = cc < p.c1; }
+        const int off = p.tap_off[ld_tap];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tin = at[i] + off;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cvalid && tin >= 0 && tin < p.T_in) {
+                const int row = arow_base[i] + tin;
+                v = *reinterpret_cast<const f32x4*>(src + (size_t)row * ld + cc);
+                if (A_NORM) { const float mu = p.a_mean[row], rs = p.a_rstd[row]; v = (v - mu) * rs; }
+                if (A_MASK) { v *= p.a_mask[row]; }
+            }
+            ra[i] = v;
+        }
+        const float* wp = wrow + ld_tap * p.ktap + ld_c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * Kp);
+        ld_c += GEMM_BK;
+        if (ld_c >= p.ktap) { ld_c = 0; ++ld_tap; }
+    };
+    auto stage = [&](int buf) {
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + GEMM_BM * LDS_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_STRIDE + lq) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lq) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = Kp / GEMM_BK;
+    fetch();
+    stage(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) fetch();
+        const float* Aw = lds + (kt & 1) * TILE_FLOATS + (wm * 64) * LDS_STRIDE + frag_off;
+        const float* Bw = lds + (kt & 1) * TILE_FLOATS + (GEMM_BM + wn * 64) * LDS_STRIDE + frag_off;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Aw + 8 * g);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Aw + 32 * LDS_STRIDE + 8 * g);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bw + 8 * g);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bw + 32 * LDS_STRIDE + 8 * g);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) stage((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  Accumulator map (32x32 tile): column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Each wave parks its 64x64 tile in LDS (free after the last barrier) and re-reads it as float4 rows, so that the
+    // epilogue math runs on 4 consecutive columns per lane and every store instruction writes whole 256-byte row pieces.
+    constexpr int CS = 68;   // row stride of the parked tile (floats)
+    float* Cw = lds + wave * (64 * CS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + j * 32 + (lane & 31)] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+
+    const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+    const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (nc + e < p.N) {
+            if (p.bias) bias4[e] = p.bias[nc + e];
+            if (p.act == ACT_SNAKE) { s0[e] = p.p0[nc + e]; s1[e] = p.p1[nc + e]; }
+        }
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int m = m0 + wm * 64 + rl;
+        if (m >= M || nc >= p.N) continue;
+        int orow = m;
+        if (!plain_rows) {
+            const int b = m / p.T_out;
+            orow = b * p.out_T + (m - b * p.T_out) * p.out_stride + p.out_off;
+        }
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * CS + (lane & 15) * 4);
+        const float om = p.out_mask ? p.out_mask[orow] : 1.0f;
+        float c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = act_apply(a[e] + bias4[e], p.act, s0[e], s1[e]);
+            if (p.out_mask) v *= om;
+            if (p.out_scale != 1.0f) v *= p.out_scale;
+            c[e] = v;
+        }
+        float* op = p.out + (size_t)orow * p.ldc + nc;
+        if (vec) {
+            f32x4 o = {c[0], c[1], c[2], c[3]};
+            if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)orow * p.ldr + nc);
+            *reinterpret_cast<f32x4*>(op) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nc + e < p.N) op[e] = p.res ? c[e] + p.res[(size_t)orow * p.ldr + nc + e] : c[e];
+        }
+    }
+}
+
+template <bool A_MASK, bool A_NORM>
+static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
+    static bool configured = false;   // per instantiation
+    auto kern = gemm_f32_kernel<A_MASK, A_NORM>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int M = a.B * a.T_out;
+    const int grid = ((M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    // shape contract (the kernel indexes without further checks)
+    if (!a.a0 || !a.w || !a.out || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
+    if (a.ntaps < 1 || a.ntaps > MAX_TAPS) return hipErrorInvalidValue;
+    if (a.ktap % GEMM_BK != 0 || a.ktap < a.c0 + a.c1) return hipErrorInvalidValue;
+    if ((a.c0 & 3) || (a.c1 & 3) || (a.lda0 & 3) || (a.lda1 & 3)) return hipErrorInvalidValue;
+    if (a.a1 && (a.c0 % GEMM_BK)) return hipErrorInvalidValue;
+    if (!a.a1 && a.c1) return hipErrorInvalidValue;
+    if (a.lda0 < a.c0 || (a.a1 && a.lda1 < a.c1)) return hipErrorInvalidValue;
+    if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
+    if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
+    const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr;
+    if (mk && nm) return launch_variant<true, true>(a, s);
+    if (mk) return launch_variant<true, false>(a, s);
+    if (nm) return launch_variant<false, true>(a, s);
+    return launch_variant<false, false>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT, const int* tsel, const float* col_scale,
+                      float* dst) {
+    const int ktap = round_up(C, GEMM_BK);
+    const int Kp = ntaps * ktap;
+    const int Np = round_up(N, GEMM_BN);
+    for (size_t i = 0; i < (size_t)Np * Kp; ++i) dst[i] = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int j = 0; j < ntaps; ++j)
+            for (int c = 0; c < C; ++c) {
+                float v;
+                if (kind == 0) v = w[(size_t)n * C + c];
+                else if (kind == 1) v = w[((size_t)n * C + c) * ntaps + j];
+                else v = w[((size_t)c * N + n) * kT + tsel[j]];
+                if (col_scale) v *= col_scale[c];
+                dst[(size_t)n * Kp + j * ktap + c] = v;
+            }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int N, int C, int ntaps, int ktap, int Np, float* __restrict__ dst) {
+    const int Kp = ntaps * ktap;
+    const size_t total = (size_t)Np * Kp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kp);
+        const int k = (int)(i - (size_t)n * Kp);
+        const int j = k / ktap, c = k - j * ktap;
+        float v = 0.f;
+        if (n < N && c < C) v = w[((size_t)n * C + c) * ntaps + j];
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_pack_weight(const float* w, int N, int C, int ntaps, float* dst, hipStream_t s) {
+    const int ktap = round_up(C, GEMM_BK), Np = round_up(N, GEMM_BN);
+    const size_t total = (size_t)Np * ntaps * ktap;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, s, w, N, C, ntaps, ktap, Np, dst);
+    return hipGetLastError();
+}
+
+}  // namespace mtts

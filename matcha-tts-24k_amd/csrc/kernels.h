@@ -1,0 +1,132 @@
+// Internal kernel-launch interface of libmtts_hip.so (gfx950 only).
+// Every launcher enqueues on the given stream and returns hipError_t; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtts {
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 32;
+constexpr int MAX_TAPS = 5;
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SNAKE = 3 };
+
+// C[M,N] = epi( pro(A)[M,K] . W[N,K]^T )   -- see gemm_f32.hip for the tiling.
+struct GemmArgs {
+    // ---- A operand: rows of channels-last activations; up to two channel segments (concat along K per tap)
+    const float* a0 = nullptr;
+    const float* a1 = nullptr;
+    int lda0 = 0, lda1 = 0;
+    int c0 = 0, c1 = 0;          // channels read from each segment (c0 % 32 == 0 whenever a1 != nullptr)
+    int ktap = 0;                // padded K per tap = round_up(c0 + c1, 32)
+    int ntaps = 1;
+    int tap_off[MAX_TAPS] = {0, 0, 0, 0, 0};
+    int in_stride = 1;           // t_in = t_out * in_stride + tap_off[tap]
+    int B = 1, T_in = 1, T_out = 1;   // M = B * T_out
+    const float* a_mask = nullptr;    // [B*T_in]  multiply A rows
+    const float* a_mean = nullptr;    // [B*T_in]  (x - mean) * rstd   (LayerNorm with the affine folded into W)
+    const float* a_rstd = nullptr;
+    // ---- B operand: packed [Np][Kp], Np = round_up(N,128), Kp = ntaps * ktap
+    const float* w = nullptr;
+    const float* bias = nullptr;      // [Np] or null
+    int N = 0;
+    // ---- epilogue: c = act(acc + bias); c *= out_mask[row]; c = c * out_scale + res[row][n]
+    int act = ACT_NONE;
+    const float* p0 = nullptr;        // snake: exp(alpha)[N]
+    const float* p1 = nullptr;        // snake: 1 / (exp(beta) + 1e-9)[N]
+    const float* out_mask = nullptr;  // [B*out_T] indexed by the output row
+    float out_scale = 1.0f;
+    const float* res = nullptr;
+    int ldr = 0;
+    float* out = nullptr;
+    int ldc = 0;
+    int out_T = 1, out_stride = 1, out_off = 0;   // output row = b*out_T + t*out_stride + out_off
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+static inline double gemm_flops(const GemmArgs& a) {
+    return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
+}
+
+// Pack a torch weight into the GEMM panel layout [Np][ntaps*ktap] (host side).
+//   kind 0: Linear [N, C]   kind 1: Conv1d [N, C, ntaps]   kind 2: ConvTranspose1d [C, N, kT] taking taps `tsel[0..ntaps)`
+void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT, const int* tsel, const float* col_scale,
+                      float* dst);
+// Device-side packing of an unpacked Linear/Conv1d weight (used by the single-kernel test entry point).
+hipError_t launch_pack_weight(const float* w, int N, int C, int ntaps, float* dst, hipStream_t s);
+
+struct AttnArgs {
+    const float* qkv = nullptr;   // [B*T, 3*H*D]
+    const float* mask = nullptr;  // [B*T] float 0/1
+    float* out = nullptr;         // [B*T, H*D]
+    int B = 0, T = 0, H = 0, D = 0;
+    float scale = 1.0f;
+    int mask_mode = 0;            // 0 additive key bias, 1 boolean query*key
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
+
+// ---- normalisation / activation / glue (norm_glue.hip)
+hipError_t launch_row_stats(const float* x, int M, int C, int ld, float eps, float* mean, float* rstd, hipStream_t s);
+
+// y = act(LN_C(x) * gamma + beta) [* film_g[b] + film_b[b]] [* mask[row]]   (channel LayerNorm of the text encoder)
+struct LayerNormArgs {
+    const float* x = nullptr; int ldx = 0;
+    float* y = nullptr; int ldy = 0;
+    int M = 0, C = 0, T = 1;           // T rows per batch element (for the FiLM lookup)
+    const float* gamma = nullptr; const float* beta = nullptr;
+    float eps = 1e-5f;
+    int act = ACT_NONE;                // ACT_SILU for the prenet
+    const float* film = nullptr;       // [B, 2C]: gamma | beta (DurationPredictor)
+    const float* mask = nullptr;       // [M]
+};
+hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
+
+// GroupNorm statistics over (C/G channels x T frames) of y [B,T,C]: partial (mean, M2) per chunk of GN_CHUNK rows.
+constexpr int GN_CHUNK = 32;
+static inline int gn_chunks(int T) { return (T + GN_CHUNK - 1) / GN_CHUNK; }
+hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s);
+// out = Mish(GN(y)) ; out = (out [+ chbias[c]]) * mask[row] ; out += res[row][c]
+struct GnApplyArgs {
+    const float* y = nullptr; const float* partial = nullptr;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    const float* mask = nullptr;      // [B*T]
+    const float* chbias = nullptr;    // [C] (time-embedding bias of the ResNet block) or null
+    const float* res = nullptr; int ldr = 0;
+    float* out = nullptr;
+    int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
+};
+hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
+
+// channels-first [B,C,T] <-> channels-last [B,T,ld] moves
+// dst[b,t,col_off + c] = src[b,c,t] (+ add[b,c,t])
+hipError_t launch_cf_to_cl(const float* src, const float* add, int B, int C, int T, float* dst, int ld, int col_off, hipStream_t s);
+// dst[b,c,t] = src[b,t,c] * scale + shift for t < T_out
+hipError_t launch_cl_to_cf(const float* src, int ld, int B, int C, int T, float* dst, int T_out, float scale, float shift, hipStream_t s);
+hipError_t launch_fill_cols(float* dst, int M, int ld, int col0, int ncols, float v, hipStream_t s);
+
+// elementwise helpers
+constexpr int MAX_EVALS = 256;
+struct TimeVals { float t[MAX_EVALS]; };
+hipError_t launch_time_sinusoid(const float* freqs, const TimeVals& tv, int nt, int half, float scale, float* out, hipStream_t s);
+hipError_t launch_unary(const float* x, float* y, int64_t n, int act_mish, hipStream_t s);
+// ODE state updates on the x columns of the channels-last state; stage semantics in norm_glue.hip
+hipError_t launch_ode_combine(int stage, float dt, const float* y, int ldy, const float* k1, const float* k2, const float* k3,
+                              const float* k4, int ldk, float* out, int ldo, int M, int C, hipStream_t s);
+
+// text-encoder glue
+hipError_t launch_embedding(const int64_t* ids, const float* table, int rows, int C, float scale, const float* mask, float* out, int ld, hipStream_t s);
+hipError_t launch_seq_mask(const int64_t* lengths, int B, int T, float* mask, hipStream_t s);
+hipError_t launch_bcast_rows(const float* src, int B, int T, int C, const float* mask, float* dst, int ld, int col_off, hipStream_t s);
+hipError_t launch_rope(float* qkv, int B, int T, int H, int D, int d_rope, const float* cos_t, const float* sin_t, hipStream_t s);
+hipError_t launch_durations(const float* logw, const float* mask, float scale_correction, float length_scale, int B, int Tx, float* dur,
+                            int32_t* cum, int64_t* yfl, hipStream_t s);
+// level mask of the U-Net: dst[b, t] = src[b, t * stride], t < T_dst (reference decoder.py:390 mask[:, :, ::2])
+hipError_t launch_mask_down(const float* src, int B, int T_src, int stride, float* dst, int T_dst, hipStream_t s);
+hipError_t launch_align_pool(const float* mu_x, const int32_t* cum, const int64_t* yfl, int B, int nf, int Tx, int T_pad,
+                             float* mu_y, float* y_mask, int64_t* y_len, hipStream_t s);
+
+}  // namespace mtts

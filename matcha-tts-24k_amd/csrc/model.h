@@ -1,0 +1,77 @@
+// Host-side model of the path: packed weights, workspace planning and the launch sequences of
+// TextEncoder.forward, Decoder.forward and BASECFM.solve (reference files cited at each function in model.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mtts.h"
+#include "kernels.h"
+
+namespace mtts {
+
+void set_error(const std::string& msg);
+const char* get_error();
+
+// One GEMM-ready weight panel inside the device image (offsets in floats).
+struct Panel {
+    size_t w = 0, b = 0;
+    bool has_bias = false;
+    int N = 0, C = 0, ntaps = 1, ktap = 0;
+};
+struct Vec { size_t off = 0; int n = 0; };
+
+struct ResnetW {
+    Panel conv1, conv2, res;
+    Vec gn1_g, gn1_b, gn2_g, gn2_b;
+    int cin = 0, cout = 0;
+    int tb_off = 0;           // column offset of this block's time bias inside the per-evaluation bias row
+};
+struct TBlockW {
+    Panel qkv, out, ff1, ff2;  // LayerNorm affines folded into qkv / ff1
+    Vec alpha_exp, inv_beta;
+};
+struct DecW {
+    Vec freqs;
+    Panel t1, t2, tmlp;        // time MLP and the concatenated per-ResNet Linear(Mish(t))
+    int tb_total = 0;
+    std::vector<ResnetW> res;            // down..., mid..., up... in execution order
+    std::vector<TBlockW> tb;             // n_blocks per resnet, execution order
+    std::vector<Panel> down;             // per level: stride-2 conv (or k3 conv at the last level)
+    std::vector<Panel> up_even, up_odd;  // ConvTranspose phases (levels-1 entries)
+    Panel up_last;                       // k3 conv of the last up block
+    Panel final_conv, final_proj;
+    Vec fgn_g, fgn_b;
+};
+struct EncW {
+    Vec emb, spk_enc, spk_dur, rope_cos, rope_sin;
+    std::vector<Panel> pre_conv;
+    std::vector<Vec> pre_g, pre_b;
+    Panel pre_proj;
+    std::vector<Panel> qkv, o, ffn1, ffn2;
+    std::vector<Vec> n1_g, n1_b, n2_g, n2_b;
+    Panel pm0, pm2;
+    Panel film;
+    std::vector<Panel> dp_conv;
+    std::vector<Vec> dp_g, dp_b;
+    Panel dp_proj;
+};
+
+struct ProfRec { hipEvent_t e0, e1; int klass; double flops; };
+
+}  // namespace mtts
+
+struct mtts_ctx {
+    mtts_config cfg;
+    std::map<std::string, std::vector<float>> raw;
+    std::vector<float> image;     // host staging of the packed device image
+    float* d_image = nullptr;     // caller-owned device buffer
+    bool packed = false, uploaded = false;
+    mtts::DecW dec;
+    mtts::EncW enc;
+    // profiling
+    bool prof_on = false;
+    std::vector<mtts::ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};

@@ -1,0 +1,952 @@
+// Host orchestration of the path on one HIP stream: weight packing, workspace planning and the launch sequences.
+// No torch, no allocation or synchronisation inside the launch functions (graph-capturable).
+#include "model.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace mtts {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+const char* get_error() { return g_err.c_str(); }
+
+#define HIP_OK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+#define RET_IF(expr)          \
+    do {                      \
+        int _r = (expr);      \
+        if (_r) return _r;    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ profiling wrappers
+static int prof_begin(mtts_ctx* c, int klass, double flops, hipStream_t s) {
+    if (!c || !c->prof_on) return 0;
+    while (c->ev_pool.size() < c->ev_used + 2) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    ProfRec r{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], klass, flops};
+    c->ev_used += 2;
+    HIP_OK(hipEventRecord(r.e0, s));
+    c->prof.push_back(r);
+    return 0;
+}
+static int prof_end(mtts_ctx* c, hipStream_t s) {
+    if (!c || !c->prof_on) return 0;
+    HIP_OK(hipEventRecord(c->prof.back().e1, s));
+    return 0;
+}
+#define LAUNCH(ctx, klass, flops, stream, call)  \
+    do {                                         \
+        RET_IF(prof_begin(ctx, klass, flops, stream)); \
+        HIP_OK(call);                            \
+        RET_IF(prof_end(ctx, stream));           \
+    } while (0)
+
+static int run_gemm(mtts_ctx* c, const GemmArgs& a, hipStream_t s) {
+    LAUNCH(c, 0, gemm_flops(a), s, launch_gemm(a, s));
+    return 0;
+}
+static int run_attn(mtts_ctx* c, const AttnArgs& a, hipStream_t s) {
+    LAUNCH(c, 1, attn_flops(a), s, launch_attention(a, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct WS {
+    char* base;
+    size_t off = 0, cap;
+    bool overflow = false;
+    WS(void* p, size_t c) : base(static_cast<char*>(p)), cap(c) {}
+    void* bytes(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        void* r = base ? base + off : nullptr;
+        off += n;
+        if (base && off > cap) overflow = true;
+        return r;
+    }
+    float* f(size_t n) { return static_cast<float*>(bytes(n * sizeof(float))); }
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing
+struct Packer {
+    mtts_ctx* c;
+    bool ok = true;
+    std::string why;
+    explicit Packer(mtts_ctx* ctx) : c(ctx) {}
+    const std::vector<float>* get(const std::string& key, size_t numel) {
+        auto it = c->raw.find(key);
+        if (it == c->raw.end()) { fail("missing tensor " + key); return nullptr; }
+        if (it->second.size() != numel) {
+            fail("tensor " + key + " has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(numel));
+            return nullptr;
+        }
+        return &it->second;
+    }
+    void fail(const std::string& m) { if (ok) { ok = false; why = m; } }
+    size_t alloc(size_t n) {
+        size_t off = (c->image.size() + 63) & ~size_t(63);
+        c->image.resize(off + n, 0.f);
+        return off;
+    }
+    Vec vec(const std::string& key, int n) {
+        Vec v;
+        const auto* t = get(key, n);
+        if (!t) return v;
+        v.off = alloc(n);
+        v.n = n;
+        std::memcpy(&c->image[v.off], t->data(), n * sizeof(float));
+        return v;
+    }
+    // kind 0 Linear [N,C]; 1 Conv1d [N,C,ntaps]; 2 ConvTranspose1d [C,N,kT] with taps tsel
+    Panel panel(const std::string& wkey, const std::string& bkey, int kind, int N, int C, int ntaps, int kT = 0,
+                const int* tsel = nullptr, const std::vector<float>* col_scale = nullptr,
+                const std::vector<float>* col_shift = nullptr) {
+        return panel_multi({wkey}, {bkey}, kind, N, C, ntaps, kT, tsel, col_scale, col_shift);
+    }
+    // several [N_i, C(,k)] tensors stacked along N into one panel (q|k|v, concatenated time MLPs)
+    Panel panel_multi(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys, int kind, int N_each, int C,
+                      int ntaps, int kT = 0, const int* tsel = nullptr, const std::vector<float>* col_scale = nullptr,
+                      const std::vector<float>* col_shift = nullptr) {
+        Panel p;
+        const int parts = (int)wkeys.size();
+        p.N = N_each * parts;
+        p.C = C;
+        p.ntaps = ntaps;
+        p.ktap = round_up(C, GEMM_BK);
+        const int Np = round_up(p.N, GEMM_BN);
+        const size_t Kp = (size_t)ntaps * p.ktap;
+        p.w = alloc((size_t)Np * Kp);
+        p.b = alloc(Np);
+        const size_t per = (kind == 2) ? (size_t)C * N_each * kT : (size_t)N_each * C * ntaps;
+        std::vector<float> tmp((size_t)round_up(N_each, GEMM_BN) * Kp);
+        for (int part = 0; part < parts; ++part) {
+            const auto* w = get(wkeys[part], per);
+            if (!w) return p;
+            pack_weight_host(w->data(), kind, N_each, C, ntaps, kT, tsel, col_scale ? col_scale->data() : nullptr, tmp.data());
+            std::memcpy(&c->image[p.w + (size_t)part * N_each * Kp], tmp.data(), (size_t)N_each * Kp * sizeof(float));
+            const bool hb = part < (int)bkeys.size() && !bkeys[part].empty();
+            const std::vector<float>* b = hb ? get(bkeys[part], N_each) : nullptr;
+            if (hb && !b) return p;
+            if (hb || col_shift) p.has_bias = true;
+            for (int n = 0; n < N_each; ++n) {
+                double acc = b ? (double)(*b)[n] : 0.0;
+                if (col_shift) {   // LayerNorm beta folded through the projection: b' = b + W . beta
+                    for (int cc = 0; cc < C; ++cc) acc += (double)(*w)[(size_t)n * C + cc] * (double)(*col_shift)[cc];
+                }
+                c->image[p.b + (size_t)part * N_each + n] = (float)acc;
+            }
+        }
+        return p;
+    }
+};
+
+static int pack_all(mtts_ctx* c) {
+    const mtts_config& g = c->cfg;
+    c->image.clear();
+    Packer P(c);
+    auto S = [](const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; };
+    const int taps3[3] = {-1, 0, 1};
+    (void)taps3;
+
+    // ---------------- text encoder (reference text_encoder.py:319-373)
+    EncW& E = c->enc;
+    E = EncW();
+    const int nch = g.enc_channels, Sd = g.spk_emb_dim, Hd = nch + Sd, F = g.dp_filter;
+    const int dh = Hd / g.enc_heads, d_rope = dh / 2;
+    E.emb = P.vec("encoder.emb.weight", g.n_vocab * nch);
+    E.spk_enc = P.vec("speaker_embeddings_enc.weight", g.n_spks * Sd);
+    E.spk_dur = P.vec("speaker_embeddings_dur.weight", g.n_spks * Sd);
+    {
+        auto it = c->raw.find("aux.rope_cos");
+        if (it == c->raw.end() || it->second.size() % d_rope) P.fail("aux.rope_cos missing or misshaped");
+        else {
+            E.rope_cos = P.vec("aux.rope_cos", (int)it->second.size());
+            E.rope_sin = P.vec("aux.rope_sin", (int)it->second.size());
+        }
+    }
+    for (int i = 0; i < g.prenet_layers; ++i) {
+        E.pre_conv.push_back(P.panel(S("encoder.prenet.conv_layers.", i, ".weight"), S("encoder.prenet.conv_layers.", i, ".bias"), 1, nch, nch, g.prenet_kernel));
+        E.pre_g.push_back(P.vec(S("encoder.prenet.norm_layers.", i, ".gamma"), nch));
+        E.pre_b.push_back(P.vec(S("encoder.prenet.norm_layers.", i, ".beta"), nch));
+    }
+    E.pre_proj = P.panel("encoder.prenet.proj.weight", "encoder.prenet.proj.bias", 1, nch, nch, 1);
+    for (int i = 0; i < g.enc_layers; ++i) {
+        const std::string a = S("encoder.encoder.attn_layers.", i, ".");
+        E.qkv.push_back(P.panel_multi({a + "conv_q.weight", a + "conv_k.weight", a + "conv_v.weight"},
+                                      {a + "conv_q.bias", a + "conv_k.bias", a + "conv_v.bias"}, 1, Hd, Hd, 1));
+        E.o.push_back(P.panel(a + "conv_o.weight", a + "conv_o.bias", 1, Hd, Hd, 1));
+        E.n1_g.push_back(P.vec(S("encoder.encoder.norm_layers_1.", i, ".gamma"), Hd));
+        E.n1_b.push_back(P.vec(S("encoder.encoder.norm_layers_1.", i, ".beta"), Hd));
+        const std::string f = S("encoder.encoder.ffn_layers.", i, ".");
+        E.ffn1.push_back(P.panel(f + "conv_1.weight", f + "conv_1.bias", 1, g.enc_filter, Hd, g.enc_kernel));
+        E.ffn2.push_back(P.panel(f + "conv_2.weight", f + "conv_2.bias", 1, Hd, g.enc_filter, g.enc_kernel));
+        E.n2_g.push_back(P.vec(S("encoder.encoder.norm_layers_2.", i, ".gamma"), Hd));
+        E.n2_b.push_back(P.vec(S("encoder.encoder.norm_layers_2.", i, ".beta"), Hd));
+    }
+    E.pm0 = P.panel("encoder.proj_m.0.weight", "encoder.proj_m.0.bias", 1, nch, Hd, 1);
+    E.pm2 = P.panel("encoder.proj_m.2.weight", "encoder.proj_m.2.bias", 1, g.n_feats, nch, 1);
+    E.film = P.panel("encoder.proj_w.spk_proj.weight", "encoder.proj_w.spk_proj.bias", 0, 2 * F, Sd, 1);
+    for (int i = 0; i < g.dp_layers; ++i) {
+        E.dp_conv.push_back(P.panel(S("encoder.proj_w.conv_layers.", i, ".weight"), S("encoder.proj_w.conv_layers.", i, ".bias"), 1, F,
+                                    i == 0 ? Hd : F, g.dp_kernel));
+        E.dp_g.push_back(P.vec(S("encoder.proj_w.norm_layers.", i, ".gamma"), F));
+        E.dp_b.push_back(P.vec(S("encoder.proj_w.norm_layers.", i, ".beta"), F));
+    }
+    E.dp_proj = P.panel("encoder.proj_w.proj.weight", "encoder.proj_w.proj.bias", 1, 1, F, 1);
+
+    // ---------------- decoder (reference decoder.py:202-310)
+    DecW& D = c->dec;
+    D = DecW();
+    const std::string R = "decoder.estimator.";
+    const int cin0 = 2 * g.n_feats, nl = g.dec_levels, temb = g.dec_channels[0] * 4;
+    const int inner = g.dec_heads * g.dec_head_dim;
+    D.freqs = P.vec("aux.time_freqs", cin0 / 2);
+    D.t1 = P.panel(R + "time_mlp.linear_1.weight", R + "time_mlp.linear_1.bias", 0, temb, cin0, 1);
+    D.t2 = P.panel(R + "time_mlp.linear_2.weight", R + "time_mlp.linear_2.bias", 0, temb, temb, 1);
+
+    std::vector<std::string> mlp_w, mlp_b;
+    std::vector<int> mlp_n;
+    auto resnet = [&](const std::string& p, int ci, int co) {
+        ResnetW r;
+        r.cin = ci;
+        r.cout = co;
+        r.conv1 = P.panel(p + "block1.block.0.weight", p + "block1.block.0.bias", 1, co, ci, 3);
+        r.gn1_g = P.vec(p + "block1.block.1.weight", co);
+        r.gn1_b = P.vec(p + "block1.block.1.bias", co);
+        r.conv2 = P.panel(p + "block2.block.0.weight", p + "block2.block.0.bias", 1, co, co, 3);
+        r.gn2_g = P.vec(p + "block2.block.1.weight", co);
+        r.gn2_b = P.vec(p + "block2.block.1.bias", co);
+        r.res = P.panel(p + "res_conv.weight", p + "res_conv.bias", 1, co, ci, 1);
+        mlp_w.push_back(p + "mlp.1.weight");
+        mlp_b.push_back(p + "mlp.1.bias");
+        mlp_n.push_back(co);
+        D.res.push_back(r);
+    };
+    auto tblock = [&](const std::string& p, int ch) {
+        TBlockW t;
+        const auto* g1 = P.get(p + "norm1.weight", ch);
+        const auto* b1 = P.get(p + "norm1.bias", ch);
+        const auto* g3 = P.get(p + "norm3.weight", ch);
+        const auto* b3 = P.get(p + "norm3.bias", ch);
+        if (!g1 || !b1 || !g3 || !b3) return;
+        // nn.LayerNorm affine folded into the projection that consumes it: W' = W * gamma (per column), b' = b + W . beta
+        t.qkv = P.panel_multi({p + "attn1.to_q.weight", p + "attn1.to_k.weight", p + "attn1.to_v.weight"}, {}, 0, inner, ch, 1, 0,
+                              nullptr, g1, b1);
+        t.out = P.panel(p + "attn1.to_out.0.weight", p + "attn1.to_out.0.bias", 0, ch, inner, 1);
+        t.ff1 = P.panel(p + "ff.net.0.proj.weight", p + "ff.net.0.proj.bias", 0, 4 * ch, ch, 1, 0, nullptr, g3, b3);
+        t.alpha_exp = P.vec(p + "ff.net.0.alpha_exp", 4 * ch);
+        t.inv_beta = P.vec(p + "ff.net.0.inv_beta", 4 * ch);
+        t.ff2 = P.panel(p + "ff.net.2.weight", p + "ff.net.2.bias", 0, ch, 4 * ch, 1);
+        D.tb.push_back(t);
+    };
+    int co = cin0;
+    for (int i = 0; i < nl; ++i) {
+        const int ci = co;
+        co = g.dec_channels[i];
+        resnet(R + S("down_blocks.", i, ".0."), ci, co);
+        for (int j = 0; j < g.dec_n_blocks; ++j) tblock(R + S("down_blocks.", i, ".1.") + std::to_string(j) + ".", co);
+        if (i < nl - 1) D.down.push_back(P.panel(R + S("down_blocks.", i, ".2.conv.weight"), R + S("down_blocks.", i, ".2.conv.bias"), 1, co, co, 3));
+        else D.down.push_back(P.panel(R + S("down_blocks.", i, ".2.weight"), R + S("down_blocks.", i, ".2.bias"), 1, co, co, 3));
+    }
+    const int cmid = g.dec_channels[nl - 1];
+    for (int i = 0; i < g.dec_mid_blocks; ++i) {
+        resnet(R + S("mid_blocks.", i, ".0."), cmid, cmid);
+        for (int j = 0; j < g.dec_n_blocks; ++j) tblock(R + S("mid_blocks.", i, ".1.") + std::to_string(j) + ".", cmid);
+    }
+    for (int i = 0; i < nl; ++i) {       // up path: channels reversed + channels[0]
+        const int ci = g.dec_channels[nl - 1 - i];
+        const int cu = (i + 1 < nl) ? g.dec_channels[nl - 2 - i] : g.dec_channels[0];
+        resnet(R + S("up_blocks.", i, ".0."), 2 * ci, cu);
+        for (int j = 0; j < g.dec_n_blocks; ++j) tblock(R + S("up_blocks.", i, ".1.") + std::to_string(j) + ".", cu);
+        if (i < nl - 1) {
+            // ConvTranspose1d(k4, s2, p1): out[2j] = W1.x[j] + W3.x[j-1];  out[2j+1] = W0.x[j+1] + W2.x[j]
+            const int even[2] = {1, 3}, odd[2] = {0, 2};
+            D.up_even.push_back(P.panel(R + S("up_blocks.", i, ".2.conv.weight"), R + S("up_blocks.", i, ".2.conv.bias"), 2, cu, cu, 2, 4, even));
+            D.up_odd.push_back(P.panel(R + S("up_blocks.", i, ".2.conv.weight"), R + S("up_blocks.", i, ".2.conv.bias"), 2, cu, cu, 2, 4, odd));
+        } else {
+            D.up_last = P.panel(R + S("up_blocks.", i, ".2.weight"), R + S("up_blocks.", i, ".2.bias"), 1, cu, cu, 3);
+        }
+    }
+    const int cfin = g.dec_channels[0];
+    D.final_conv = P.panel(R + "final_block.block.0.weight", R + "final_block.block.0.bias", 1, cfin, cfin, 3);
+    D.fgn_g = P.vec(R + "final_block.block.1.weight", cfin);
+    D.fgn_b = P.vec(R + "final_block.block.1.bias", cfin);
+    D.final_proj = P.panel(R + "final_proj.weight", R + "final_proj.bias", 1, g.n_feats, cfin, 1);
+    // per-ResNet Linear(Mish(t)) stacked into one [sum(cout), temb] panel (rows of different blocks may differ in count)
+    {
+        int total = 0;
+        for (size_t i = 0; i < D.res.size(); ++i) { D.res[i].tb_off = total; total += mlp_n[i]; }
+        D.tb_total = total;
+        Panel p;
+        p.N = total; p.C = temb; p.ntaps = 1; p.ktap = round_up(temb, GEMM_BK); p.has_bias = true;
+        p.w = P.alloc((size_t)round_up(total, GEMM_BN) * p.ktap);
+        p.b = P.alloc(round_up(total, GEMM_BN));
+        for (size_t i = 0; i < D.res.size() && P.ok; ++i) {
+            const auto* w = P.get(mlp_w[i], (size_t)mlp_n[i] * temb);
+            const auto* b = P.get(mlp_b[i], mlp_n[i]);
+            if (!w || !b) break;
+            for (int n = 0; n < mlp_n[i]; ++n) {
+                std::memcpy(&c->image[p.w + (size_t)(D.res[i].tb_off + n) * p.ktap], &(*w)[(size_t)n * temb], temb * sizeof(float));
+                c->image[p.b + D.res[i].tb_off + n] = (*b)[n];
+            }
+        }
+        D.tmlp = p;
+    }
+    if (!P.ok) { set_error(P.why); return -1; }
+    c->packed = true;
+    return 0;
+}
+
+static inline const float* W(const mtts_ctx* c, size_t off) { return c->d_image + off; }
+
+static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
+    a.w = W(c, p.w);
+    a.bias = p.has_bias ? W(c, p.b) : nullptr;
+    a.N = p.N;
+    a.ntaps = p.ntaps;
+    a.ktap = p.ktap;
+}
+static void rows_plain(GemmArgs& a, int B, int T) {
+    a.B = B; a.T_in = T; a.T_out = T; a.in_stride = 1;
+    a.out_T = T; a.out_stride = 1; a.out_off = 0;
+}
+static void taps_centered(GemmArgs& a, int k) {
+    for (int j = 0; j < k; ++j) a.tap_off[j] = j - k / 2;
+}
+
+// ================================================================================================ decoder
+struct DecBufs {
+    int B = 0, T = 0, nl = 0;
+    std::vector<int> Tl;                 // frames per level
+    std::vector<float*> mask;            // [B*T_l]
+    std::vector<float*> bufA, bufB, skip;
+    float *Y = nullptr, *Hh = nullptr, *Rr = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
+    float *mean = nullptr, *rstd = nullptr, *gnp = nullptr;
+    float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
+    int ldx = 0, ldv = 0;
+};
+
+static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_state, int n_vel, WS& ws, DecBufs& d) {
+    const mtts_config& g = c->cfg;
+    d.B = B; d.T = T; d.nl = g.dec_levels;
+    if (T % (1 << (d.nl - 1))) { set_error("T must be a multiple of 2^(levels-1) (reference utils/model.py:15-21)"); return -1; }
+    int cmax = 0;
+    for (int i = 0; i < d.nl; ++i) cmax = std::max(cmax, g.dec_channels[i]);
+    const int inner = g.dec_heads * g.dec_head_dim;
+    const size_t M0 = (size_t)B * T;
+    d.Tl.resize(d.nl);
+    d.mask.resize(d.nl); d.bufA.resize(d.nl); d.bufB.resize(d.nl); d.skip.resize(d.nl);
+    for (int l = 0; l < d.nl; ++l) {
+        d.Tl[l] = T >> l;
+        const size_t Ml = (size_t)B * d.Tl[l];
+        d.mask[l] = ws.f(Ml);
+        d.bufA[l] = ws.f(Ml * cmax);
+        d.bufB[l] = ws.f(Ml * cmax);
+        d.skip[l] = ws.f(Ml * cmax);
+    }
+    d.Y = ws.f(M0 * cmax); d.Hh = ws.f(M0 * cmax); d.Rr = ws.f(M0 * cmax);
+    d.QKV = ws.f(M0 * 3 * inner); d.ATT = ws.f(M0 * inner); d.FF = ws.f(M0 * 4 * cmax);
+    d.mean = ws.f(M0); d.rstd = ws.f(M0);
+    d.gnp = ws.f((size_t)B * gn_chunks(T) * 8 * 2);
+    d.ldx = round_up(2 * g.n_feats, GEMM_BK);
+    d.ldv = round_up(g.n_feats, 4);
+    d.xmu = ws.f(M0 * d.ldx);
+    if (n_state > 1) d.xmu2 = ws.f(M0 * d.ldx);
+    for (int i = 0; i < n_vel; ++i) d.vel[i] = ws.f(M0 * d.ldv);
+    const int temb = g.dec_channels[0] * 4;
+    d.TS = ws.f((size_t)max_evals * 2 * g.n_feats);
+    d.T1 = ws.f((size_t)max_evals * temb); d.T2 = ws.f((size_t)max_evals * temb); d.T3 = ws.f((size_t)max_evals * temb);
+    d.TB = ws.f((size_t)max_evals * c->dec.tb_total);
+    return 0;
+}
+
+// SinusoidalPosEmb + TimestepEmbedding + every ResNet's Linear(Mish(t)) for all evaluation times at once
+// (reference decoder.py:14-29,107-119,51,60): they depend on t only, so the whole ODE grid is done before the loop.
+static int time_embed(mtts_ctx* c, DecBufs& d, const TimeVals& tv, int nt, hipStream_t s) {
+    const mtts_config& g = c->cfg;
+    const DecW& D = c->dec;
+    const int cin0 = 2 * g.n_feats, temb = g.dec_channels[0] * 4;
+    LAUNCH(c, 2, 0, s, launch_time_sinusoid(W(c, D.freqs.off), tv, nt, cin0 / 2, 1000.0f, d.TS, s));
+    GemmArgs a;
+    panel_args(c, D.t1, a); rows_plain(a, nt, 1);
+    a.a0 = d.TS; a.lda0 = cin0; a.c0 = cin0; a.act = ACT_SILU; a.out = d.T1; a.ldc = temb;
+    RET_IF(run_gemm(c, a, s));
+    GemmArgs b;
+    panel_args(c, D.t2, b); rows_plain(b, nt, 1);
+    b.a0 = d.T1; b.lda0 = temb; b.c0 = temb; b.out = d.T2; b.ldc = temb;
+    RET_IF(run_gemm(c, b, s));
+    LAUNCH(c, 2, 0, s, launch_unary(d.T2, d.T3, (int64_t)nt * temb, 1, s));
+    GemmArgs m;
+    panel_args(c, D.tmlp, m); rows_plain(m, nt, 1);
+    m.a0 = d.T3; m.lda0 = temb; m.c0 = temb; m.out = d.TB; m.ldc = D.tb_total;
+    RET_IF(run_gemm(c, m, s));
+    return 0;
+}
+
+// ResnetBlock1D.forward (reference decoder.py:58-63) on channels-last rows; input = up to two channel segments.
+static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* in0, int ld0, int c0, const float* in1, int ld1,
+                        int c1, int lvl, const float* tbias, float* out, hipStream_t s) {
+    const int B = d.B, T = d.Tl[lvl], C = r.cout;
+    const float* mask = d.mask[lvl];
+    GemmArgs a;
+    panel_args(c, r.conv1, a); rows_plain(a, B, T); taps_centered(a, 3);
+    a.a0 = in0; a.lda0 = ld0; a.c0 = c0; a.a1 = in1; a.lda1 = ld1; a.c1 = c1; a.a_mask = mask;
+    a.out = d.Y; a.ldc = C;
+    RET_IF(run_gemm(c, a, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    GnApplyArgs g1;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask;
+    g1.chbias = tbias; g1.out = d.Hh; g1.B = B; g1.T = T; g1.C = C;
+    LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
+    GemmArgs b;
+    panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
+    b.a0 = d.Hh; b.lda0 = C; b.c0 = C; b.out = d.Y; b.ldc = C;      // Hh is already masked
+    RET_IF(run_gemm(c, b, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    GemmArgs rc;
+    panel_args(c, r.res, rc); rows_plain(rc, B, T);
+    rc.a0 = in0; rc.lda0 = ld0; rc.c0 = c0; rc.a1 = in1; rc.lda1 = ld1; rc.c1 = c1; rc.a_mask = mask;
+    rc.out = d.Rr; rc.ldc = C;
+    RET_IF(run_gemm(c, rc, s));
+    GnApplyArgs g2;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask;
+    g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
+    LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
+    return 0;
+}
+
+// BasicTransformerBlock.forward (reference transformer.py:230-303, self-attention only), in place on x [B*T, C].
+static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x, int C, int lvl, hipStream_t s) {
+    const mtts_config& g = c->cfg;
+    const int B = d.B, T = d.Tl[lvl], M = B * T, inner = g.dec_heads * g.dec_head_dim;
+    LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
+    GemmArgs q;
+    panel_args(c, t.qkv, q); rows_plain(q, B, T);
+    q.a0 = x; q.lda0 = C; q.c0 = C; q.a_mean = d.mean; q.a_rstd = d.rstd; q.out = d.QKV; q.ldc = 3 * inner;
+    RET_IF(run_gemm(c, q, s));
+    AttnArgs at;
+    at.qkv = d.QKV; at.mask = d.mask[lvl]; at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
+    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0;
+    RET_IF(run_attn(c, at, s));
+    GemmArgs o;
+    panel_args(c, t.out, o); rows_plain(o, B, T);
+    o.a0 = d.ATT; o.lda0 = inner; o.c0 = inner; o.res = x; o.ldr = C; o.out = x; o.ldc = C;
+    RET_IF(run_gemm(c, o, s));
+    LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
+    GemmArgs f1;
+    panel_args(c, t.ff1, f1); rows_plain(f1, B, T);
+    f1.a0 = x; f1.lda0 = C; f1.c0 = C; f1.a_mean = d.mean; f1.a_rstd = d.rstd; f1.act = ACT_SNAKE;
+    f1.p0 = W(c, t.alpha_exp.off); f1.p1 = W(c, t.inv_beta.off); f1.out = d.FF; f1.ldc = 4 * C;
+    RET_IF(run_gemm(c, f1, s));
+    GemmArgs f2;
+    panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
+    f2.a0 = d.FF; f2.lda0 = 4 * C; f2.c0 = 4 * C; f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C;
+    RET_IF(run_gemm(c, f2, s));
+    return 0;
+}
+
+struct FinalOut {   // where the masked velocity goes: out = v * scale (+ res)
+    float* out; int ldc; const float* res; int ldr; float scale;
+};
+
+// Decoder.forward (reference decoder.py:359-426) for evaluation `ev` (row of the precomputed time biases).
+// xin: channels-last state [B*T, ldx] holding x | mu.
+static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s) {
+    const mtts_config& g = c->cfg;
+    const DecW& D = c->dec;
+    const int nl = d.nl, nb = g.dec_n_blocks, B = d.B;
+    const float* tb = d.TB + (size_t)ev * D.tb_total;
+    size_t ri = 0, ti = 0;
+    const float* cur = xin;
+    int cur_ld = d.ldx, cur_c = 2 * g.n_feats;
+    // ---- down path
+    for (int l = 0; l < nl; ++l) {
+        const ResnetW& r = D.res[ri++];
+        RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, nullptr, 0, 0, l, tb + r.tb_off, d.skip[l], s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], d.skip[l], r.cout, l, s));
+        GemmArgs a;
+        panel_args(c, D.down[l], a);
+        taps_centered(a, 3);
+        a.a0 = d.skip[l]; a.lda0 = r.cout; a.c0 = r.cout; a.a_mask = d.mask[l];
+        a.B = B; a.T_in = d.Tl[l];
+        if (l < nl - 1) {   // Downsample1D: Conv1d(k3, s2, p1) (reference decoder.py:66-72)
+            a.T_out = d.Tl[l + 1]; a.in_stride = 2; a.out_T = d.Tl[l + 1];
+            a.out = d.bufA[l + 1];
+        } else {            // last level: Conv1d(k3, p1) (reference decoder.py:252-254)
+            a.T_out = d.Tl[l]; a.out_T = d.Tl[l];
+            a.out = d.bufA[l];
+        }
+        a.ldc = r.cout;
+        RET_IF(run_gemm(c, a, s));
+        cur = a.out; cur_ld = r.cout; cur_c = r.cout;
+    }
+    // ---- mid blocks at the coarsest level
+    const int lm = nl - 1;
+    for (int i = 0; i < g.dec_mid_blocks; ++i) {
+        const ResnetW& r = D.res[ri++];
+        float* dst = (cur == d.bufA[lm]) ? d.bufB[lm] : d.bufA[lm];
+        RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, nullptr, 0, 0, lm, tb + r.tb_off, dst, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, lm, s));
+        cur = dst; cur_ld = r.cout; cur_c = r.cout;
+    }
+    // ---- up path
+    for (int i = 0; i < nl; ++i) {
+        const int l = nl - 1 - i;
+        const ResnetW& r = D.res[ri++];
+        const int cskip = g.dec_channels[l];
+        float* dst = (cur == d.bufA[l]) ? d.bufB[l] : d.bufA[l];
+        RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, d.skip[l], cskip, cskip, l, tb + r.tb_off, dst, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, l, s));
+        if (i < nl - 1) {   // Upsample1D: ConvTranspose1d(k4, s2, p1) as two phase GEMMs (reference decoder.py:146)
+            float* up = d.bufA[l - 1];
+            for (int ph = 0; ph < 2; ++ph) {
+                GemmArgs a;
+                panel_args(c, ph == 0 ? D.up_even[i] : D.up_odd[i], a);
+                a.a0 = dst; a.lda0 = r.cout; a.c0 = r.cout; a.a_mask = d.mask[l];
+                a.B = B; a.T_in = d.Tl[l]; a.T_out = d.Tl[l]; a.in_stride = 1;
+                a.tap_off[0] = ph == 0 ? 0 : 1;
+                a.tap_off[1] = ph == 0 ? -1 : 0;
+                a.out = up; a.ldc = r.cout; a.out_T = d.Tl[l - 1]; a.out_stride = 2; a.out_off = ph;
+                RET_IF(run_gemm(c, a, s));
+            }
+            cur = up;
+        } else {
+            GemmArgs a;
+            panel_args(c, D.up_last, a); rows_plain(a, B, d.Tl[l]); taps_centered(a, 3);
+            a.a0 = dst; a.lda0 = r.cout; a.c0 = r.cout; a.a_mask = d.mask[l];
+            float* o2 = (dst == d.bufA[l]) ? d.bufB[l] : d.bufA[l];
+            a.out = o2; a.ldc = r.cout;
+            RET_IF(run_gemm(c, a, s));
+            cur = o2;
+        }
+        cur_ld = r.cout; cur_c = r.cout;
+    }
+    // ---- final Block1D + 1x1 projection + mask (reference decoder.py:423-426)
+    const int C0 = g.dec_channels[0], T = d.T;
+    GemmArgs a;
+    panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
+    a.a0 = cur; a.lda0 = cur_ld; a.c0 = C0; a.a_mask = d.mask[0]; a.out = d.Y; a.ldc = C0;
+    RET_IF(run_gemm(c, a, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s));
+    GnApplyArgs ga;
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0];
+    ga.out = d.Hh; ga.B = B; ga.T = T; ga.C = C0;
+    LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
+    GemmArgs p;
+    panel_args(c, D.final_proj, p); rows_plain(p, B, T);
+    p.a0 = d.Hh; p.lda0 = C0; p.c0 = C0; p.out_mask = d.mask[0];
+    p.out = fo.out; p.ldc = fo.ldc; p.res = fo.res; p.ldr = fo.ldr; p.out_scale = fo.scale;
+    RET_IF(run_gemm(c, p, s));
+    return 0;
+}
+
+static int build_masks(mtts_ctx* c, DecBufs& d, const float* mask, hipStream_t s) {
+    for (int l = 0; l < d.nl; ++l)
+        LAUNCH(c, 2, 0, s, launch_mask_down(mask, d.B, d.T, 1 << l, d.mask[l], d.Tl[l], s));
+    return 0;
+}
+
+static int check_ready(const mtts_ctx* c) {
+    if (!c) { set_error("null context"); return -1; }
+    if (!c->uploaded || !c->d_image) { set_error("weights not uploaded (mtts_upload_weights)"); return -1; }
+    return 0;
+}
+
+}  // namespace mtts
+
+using namespace mtts;
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int mtts_abi_version(void) { return MTTS_ABI_VERSION; }
+const char* mtts_last_error(void) { return get_error(); }
+
+mtts_ctx* mtts_create(const mtts_config* cfg) {
+    if (!cfg) { set_error("null config"); return nullptr; }
+    const mtts_config& g = *cfg;
+    std::string why;
+    if (g.dec_levels < 1 || g.dec_levels > 4) why = "dec_levels must be 1..4";
+    else if (g.n_feats <= 0 || (2 * g.n_feats) % 4) why = "n_feats must be even";
+    else if ((g.enc_channels + g.spk_emb_dim) % g.enc_heads) why = "encoder hidden size not divisible by heads";
+    else if (((g.enc_channels + g.spk_emb_dim) / g.enc_heads) % 4 || (g.enc_channels + g.spk_emb_dim) / g.enc_heads > 64) why = "encoder head dim must be a multiple of 4, <= 64";
+    else if (g.dec_head_dim % 4 || g.dec_head_dim > 64) why = "decoder head dim must be a multiple of 4, <= 64";
+    else if (g.enc_channels % 4 || g.spk_emb_dim % 4 || g.enc_filter % 4 || g.dp_filter % 4) why = "channel counts must be multiples of 4";
+    else if (g.enc_kernel > MAX_TAPS || g.prenet_kernel > MAX_TAPS || g.dp_kernel > MAX_TAPS) why = "kernel sizes above 5 unsupported";
+    for (int i = 0; why.empty() && i < g.dec_levels; ++i)
+        if (g.dec_channels[i] % 32) why = "decoder channels must be multiples of 32 (8 GroupNorm groups of 4k channels, K segments of 32)";
+    if (!why.empty()) { set_error(why); return nullptr; }
+    mtts_ctx* c = new mtts_ctx();
+    c->cfg = g;
+    return c;
+}
+
+void mtts_destroy(mtts_ctx* c) {
+    if (!c) return;
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int mtts_set_tensor(mtts_ctx* c, const char* key, const float* h, int64_t numel) {
+    if (!c || !key || !h || numel < 0) { set_error("mtts_set_tensor: bad argument"); return -1; }
+    c->raw[key].assign(h, h + numel);
+    c->packed = false;
+    c->uploaded = false;
+    return 0;
+}
+
+int64_t mtts_weights_bytes(mtts_ctx* c) {
+    if (!c) { set_error("null context"); return -1; }
+    if (!c->packed && pack_all(c)) return -1;
+    return (int64_t)(c->image.size() * sizeof(float));
+}
+
+int mtts_upload_weights(mtts_ctx* c, void* d_weights, int64_t bytes) {
+    if (!c || !d_weights) { set_error("mtts_upload_weights: bad argument"); return -1; }
+    if (!c->packed && pack_all(c)) return -1;
+    if ((size_t)bytes < c->image.size() * sizeof(float)) { set_error("weight buffer too small"); return -1; }
+    HIP_OK(hipMemcpy(d_weights, c->image.data(), c->image.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->d_image = static_cast<float*>(d_weights);
+    c->uploaded = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder entry points
+int64_t mtts_decoder_workspace_bytes(mtts_ctx* c, int B, int T) {
+    if (!c || (!c->packed && pack_all(c))) return -1;
+    WS ws(nullptr, 0);
+    DecBufs d;
+    if (plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d)) return -1;
+    return (int64_t)ws.off + 256;
+}
+
+int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, const float* d_mu, float t, int B, int T,
+                         float* d_out, void* d_ws, int64_t ws_bytes, void* stream) {
+    RET_IF(check_ready(c));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WS ws(d_ws, (size_t)ws_bytes);
+    DecBufs d;
+    RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
+    if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
+    const int nf = c->cfg.n_feats;
+    RET_IF(build_masks(c, d, d_mask, s));
+    LAUNCH(c, 2, 0, s, launch_fill_cols(d.xmu, B * T, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
+    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_x, nullptr, B, nf, T, d.xmu, d.ldx, 0, s));
+    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mu, nullptr, B, nf, T, d.xmu, d.ldx, nf, s));
+    TimeVals tv;
+    tv.t[0] = t;
+    RET_IF(time_embed(c, d, tv, 1, s));
+    FinalOut fo{d.vel[0], d.ldv, nullptr, 0, 1.0f};
+    RET_IF(decoder_eval(c, d, d.xmu, 0, fo, s));
+    LAUNCH(c, 2, 0, s, launch_cl_to_cf(d.vel[0], d.ldv, B, nf, T, d_out, T, 1.0f, 0.0f, s));
+    return 0;
+}
+
+int mtts_cfm_solve(mtts_ctx* c, const float* d_x0, const float* d_mu, const float* d_mask, int add_mu, const float* h_t_span,
+                   int n_steps, int solver, int B, int T, float* d_out, int T_out, float out_scale, float out_shift, void* d_ws,
+                   int64_t ws_bytes, void* stream) {
+    RET_IF(check_ready(c));
+    if (!h_t_span || n_steps < 1) { set_error("mtts_cfm_solve: bad time grid"); return -1; }
+    const int stages = solver == MTTS_SOLVER_EULER ? 1 : solver == MTTS_SOLVER_MIDPOINT ? 2 : solver == MTTS_SOLVER_RK4 ? 4 : 0;
+    if (!stages) { set_error("unsupported solver"); return -1; }
+    if (n_steps * stages > MAX_EVALS) { set_error("too many function evaluations in one solve (max 256)"); return -1; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WS ws(d_ws, (size_t)ws_bytes);
+    DecBufs d;
+    RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
+    if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
+    const int nf = c->cfg.n_feats, M = B * T;
+    RET_IF(build_masks(c, d, d_mask, s));
+    // state rows: x | mu | zero pad.  z = mu + noise when use_mu_prior (reference flow_matching.py:52-55)
+    float* states[2] = {d.xmu, d.xmu2};
+    for (int k = 0; k < (stages > 1 ? 2 : 1); ++k) {
+        LAUNCH(c, 2, 0, s, launch_fill_cols(states[k], M, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
+        LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mu, nullptr, B, nf, T, states[k], d.ldx, nf, s));
+    }
+    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_x0, add_mu ? d_mu : nullptr, B, nf, T, d.xmu, d.ldx, 0, s));
+
+    // evaluation times in torchdiffeq's fp32 arithmetic (fixed grid = t_span)
+    TimeVals tv;
+    int ne = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const float t0 = h_t_span[i], t1 = h_t_span[i + 1], dt = t1 - t0;
+        if (solver == MTTS_SOLVER_EULER) tv.t[ne++] = t0;
+        else if (solver == MTTS_SOLVER_MIDPOINT) { tv.t[ne++] = t0; tv.t[ne++] = t0 + 0.5f * dt; }
+        else {
+            const float third = 1.0f / 3.0f, two_thirds = 2.0f / 3.0f;
+            tv.t[ne++] = t0; tv.t[ne++] = t0 + dt * third; tv.t[ne++] = t0 + dt * two_thirds; tv.t[ne++] = t1;
+        }
+    }
+    RET_IF(time_embed(c, d, tv, ne, s));
+
+    int ev = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const float dt = h_t_span[i + 1] - h_t_span[i];
+        if (solver == MTTS_SOLVER_EULER) {             // y += dt * f(t0, y), fused into the last GEMM's epilogue
+            FinalOut fo{d.xmu, d.ldx, d.xmu, d.ldx, dt};
+            RET_IF(decoder_eval(c, d, d.xmu, ev++, fo, s));
+        } else if (solver == MTTS_SOLVER_MIDPOINT) {   // y_mid = y + f(t0,y)*dt/2 ; y += dt * f(t0+dt/2, y_mid)
+            FinalOut f1{d.xmu2, d.ldx, d.xmu, d.ldx, 0.5f * dt};
+            RET_IF(decoder_eval(c, d, d.xmu, ev++, f1, s));
+            FinalOut f2{d.xmu, d.ldx, d.xmu, d.ldx, dt};
+            RET_IF(decoder_eval(c, d, d.xmu2, ev++, f2, s));
+        } else {                                       // rk4, 3/8 rule
+            for (int k = 0; k < 4; ++k) {
+                FinalOut fk{d.vel[k], d.ldv, nullptr, 0, 1.0f};
+                RET_IF(decoder_eval(c, d, k == 0 ? d.xmu : d.xmu2, ev++, fk, s));
+                float* dst = k < 3 ? d.xmu2 : d.xmu;
+                LAUNCH(c, 2, 0, s, launch_ode_combine(k + 1, dt, d.xmu, d.ldx, d.vel[0], d.vel[1], d.vel[2], d.vel[3], d.ldv, dst, d.ldx, M, nf, s));
+            }
+        }
+    }
+    LAUNCH(c, 2, 0, s, launch_cl_to_cf(d.xmu, d.ldx, B, nf, T, d_out, T_out, out_scale, out_shift, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ text encoder
+struct EncBufs {
+    float *X0, *P1, *P2, *Y, *H, *H2, *QKV, *ATT, *F1, *PM, *MU, *FILM, *D1, *D2;
+};
+static void plan_encoder(const mtts_ctx* c, int B, int Tx, WS& ws, EncBufs& e) {
+    const mtts_config& g = c->cfg;
+    const size_t M = (size_t)B * Tx;
+    const int nch = g.enc_channels, Hd = nch + g.spk_emb_dim, F = g.dp_filter;
+    e.X0 = ws.f(M * nch); e.P1 = ws.f(M * nch); e.P2 = ws.f(M * nch); e.Y = ws.f(M * std::max(nch, F));
+    e.H = ws.f(M * Hd); e.H2 = ws.f(M * Hd); e.QKV = ws.f(M * 3 * Hd); e.ATT = ws.f(M * Hd);
+    e.F1 = ws.f(M * g.enc_filter); e.PM = ws.f(M * nch); e.MU = ws.f(M * round_up(g.n_feats, 4));
+    e.FILM = ws.f((size_t)B * 2 * F); e.D1 = ws.f(M * F); e.D2 = ws.f(M * F);
+}
+
+int64_t mtts_encoder_workspace_bytes(mtts_ctx* c, int B, int Tx) {
+    if (!c || (!c->packed && pack_all(c))) return -1;
+    WS ws(nullptr, 0);
+    EncBufs e;
+    plan_encoder(c, B, Tx, ws, e);
+    return (int64_t)ws.off + 256;
+}
+
+// TextEncoder.forward (reference text_encoder.py:375-406)
+int mtts_text_encoder_forward(mtts_ctx* c, const int64_t* d_x, const int64_t* d_x_lengths, const float* d_e_enc, const float* d_e_dur,
+                              int B, int Tx, float* d_mu_x, float* d_logw, float* d_x_mask, void* d_ws, int64_t ws_bytes, void* stream) {
+    RET_IF(check_ready(c));
+    const mtts_config& g = c->cfg;
+    const EncW& E = c->enc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nch = g.enc_channels, Sd = g.spk_emb_dim, Hd = nch + Sd, F = g.dp_filter, M = B * Tx;
+    const int dh = Hd / g.enc_heads, d_rope = dh / 2;
+    if ((size_t)Tx * d_rope > (size_t)E.rope_cos.n) { set_error("Phonetic representation too long, exceeds RoPE cache size"); return -1; }
+    WS ws(d_ws, (size_t)ws_bytes);
+    EncBufs e;
+    plan_encoder(c, B, Tx, ws, e);
+    if (ws.overflow) { set_error("encoder workspace too small"); return -1; }
+    float* xm = d_x_mask;   // [B,1,Tx] == rows [B*Tx]
+    LAUNCH(c, 2, 0, s, launch_seq_mask(d_x_lengths, B, Tx, xm, s));
+    LAUNCH(c, 2, 0, s, launch_embedding(d_x, W(c, E.emb.off), M, nch, sqrtf((float)nch), xm, e.X0, nch, s));
+    // ---- prenet: ConvSiluNorm (reference text_encoder.py:55-62)
+    const float* cur = e.X0;
+    for (int i = 0; i < g.prenet_layers; ++i) {
+        GemmArgs a;
+        panel_args(c, E.pre_conv[i], a); rows_plain(a, B, Tx); taps_centered(a, g.prenet_kernel);
+        a.a0 = cur; a.lda0 = nch; a.c0 = nch; a.a_mask = xm; a.out = e.Y; a.ldc = nch;
+        RET_IF(run_gemm(c, a, s));
+        float* dst = (i & 1) ? e.P2 : e.P1;
+        LayerNormArgs ln;
+        ln.x = e.Y; ln.ldx = nch; ln.y = dst; ln.ldy = nch; ln.M = M; ln.C = nch; ln.T = Tx;
+        ln.gamma = W(c, E.pre_g[i].off); ln.beta = W(c, E.pre_b[i].off); ln.act = ACT_SILU;
+        LAUNCH(c, 2, 0, s, launch_layernorm(ln, s));
+        cur = dst;
+    }
+    {
+        GemmArgs a;   // (x_org + proj(x)) * mask, written into the first n_channels columns of the hidden rows
+        panel_args(c, E.pre_proj, a); rows_plain(a, B, Tx);
+        a.a0 = cur; a.lda0 = nch; a.c0 = nch; a.out_mask = xm; a.res = e.X0; a.ldr = nch; a.out = e.H; a.ldc = Hd;
+        RET_IF(run_gemm(c, a, s));
+    }
+    LAUNCH(c, 2, 0, s, launch_bcast_rows(d_e_enc, B, Tx, Sd, xm, e.H, Hd, nch, s));
+    // ---- Encoder: post-LN transformer with RoPE attention and conv FFN (reference text_encoder.py:299-316)
+    for (int l = 0; l < g.enc_layers; ++l) {
+        GemmArgs q;
+        panel_args(c, E.qkv[l], q); rows_plain(q, B, Tx);
+        q.a0 = e.H; q.lda0 = Hd; q.c0 = Hd; q.out = e.QKV; q.ldc = 3 * Hd;
+        RET_IF(run_gemm(c, q, s));
+        LAUNCH(c, 2, 0, s, launch_rope(e.QKV, B, Tx, g.enc_heads, dh, d_rope, W(c, E.rope_cos.off), W(c, E.rope_sin.off), s));
+        AttnArgs at;
+        at.qkv = e.QKV; at.mask = xm; at.out = e.ATT; at.B = B; at.T = Tx; at.H = g.enc_heads; at.D = dh;
+        at.scale = 1.0f / sqrtf((float)dh); at.mask_mode = 1;
+        RET_IF(run_attn(c, at, s));
+        GemmArgs o;
+        panel_args(c, E.o[l], o); rows_plain(o, B, Tx);
+        o.a0 = e.ATT; o.lda0 = Hd; o.c0 = Hd; o.res = e.H; o.ldr = Hd; o.out = e.H2; o.ldc = Hd;
+        RET_IF(run_gemm(c, o, s));
+        LayerNormArgs n1;
+        n1.x = e.H2; n1.ldx = Hd; n1.y = e.H; n1.ldy = Hd; n1.M = M; n1.C = Hd; n1.T = Tx;
+        n1.gamma = W(c, E.n1_g[l].off); n1.beta = W(c, E.n1_b[l].off); n1.mask = xm;
+        LAUNCH(c, 2, 0, s, launch_layernorm(n1, s));
+        GemmArgs f1;
+        panel_args(c, E.ffn1[l], f1); rows_plain(f1, B, Tx); taps_centered(f1, g.enc_kernel);
+        f1.a0 = e.H; f1.lda0 = Hd; f1.c0 = Hd; f1.act = ACT_RELU; f1.out = e.F1; f1.ldc = g.enc_filter;
+        RET_IF(run_gemm(c, f1, s));
+        GemmArgs f2;
+        panel_args(c, E.ffn2[l], f2); rows_plain(f2, B, Tx); taps_centered(f2, g.enc_kernel);
+        f2.a0 = e.F1; f2.lda0 = g.enc_filter; f2.c0 = g.enc_filter; f2.a_mask = xm; f2.out_mask = xm;
+        f2.res = e.H; f2.ldr = Hd; f2.out = e.H2; f2.ldc = Hd;
+        RET_IF(run_gemm(c, f2, s));
+        LayerNormArgs n2 = n1;
+        n2.gamma = W(c, E.n2_g[l].off); n2.beta = W(c, E.n2_b[l].off);
+        LAUNCH(c, 2, 0, s, launch_layernorm(n2, s));
+    }
+    // ---- proj_m: 1x1 -> SiLU -> 1x1, masked (reference text_encoder.py:359-363,402)
+    {
+        GemmArgs a;
+        panel_args(c, E.pm0, a); rows_plain(a, B, Tx);
+        a.a0 = e.H; a.lda0 = Hd; a.c0 = Hd; a.act = ACT_SILU; a.out = e.PM; a.ldc = nch;
+        RET_IF(run_gemm(c, a, s));
+        GemmArgs b;
+        const int ldm = round_up(g.n_feats, 4);
+        panel_args(c, E.pm2, b); rows_plain(b, B, Tx);
+        b.a0 = e.PM; b.lda0 = nch; b.c0 = nch; b.out_mask = xm; b.out = e.MU; b.ldc = ldm;
+        RET_IF(run_gemm(c, b, s));
+        LAUNCH(c, 2, 0, s, launch_cl_to_cf(e.MU, ldm, B, g.n_feats, Tx, d_mu_x, Tx, 1.0f, 0.0f, s));
+    }
+    // ---- DurationPredictor with FiLM (reference text_encoder.py:101-112)
+    {
+        GemmArgs fm;
+        panel_args(c, E.film, fm); rows_plain(fm, B, 1);
+        fm.a0 = d_e_dur; fm.lda0 = Sd; fm.c0 = Sd; fm.out = e.FILM; fm.ldc = 2 * F;
+        RET_IF(run_gemm(c, fm, s));
+        const float* dcur = e.H;
+        int dc = Hd;
+        for (int i = 0; i < g.dp_layers; ++i) {
+            GemmArgs a;
+            panel_args(c, E.dp_conv[i], a); rows_plain(a, B, Tx); taps_centered(a, g.dp_kernel);
+            a.a0 = dcur; a.lda0 = dc; a.c0 = dc; a.a_mask = xm; a.act = ACT_RELU; a.out = e.Y; a.ldc = F;
+            RET_IF(run_gemm(c, a, s));
+            float* dst = (i & 1) ? e.D2 : e.D1;
+            LayerNormArgs ln;
+            ln.x = e.Y; ln.ldx = F; ln.y = dst; ln.ldy = F; ln.M = M; ln.C = F; ln.T = Tx;
+            ln.gamma = W(c, E.dp_g[i].off); ln.beta = W(c, E.dp_b[i].off); ln.film = e.FILM;
+            LAUNCH(c, 2, 0, s, launch_layernorm(ln, s));
+            dcur = dst;
+            dc = F;
+        }
+        GemmArgs p;
+        panel_args(c, E.dp_proj, p); rows_plain(p, B, Tx);
+        p.a0 = dcur; p.lda0 = dc; p.c0 = dc; p.a_mask = xm; p.out_mask = xm; p.out = d_logw; p.ldc = 1;
+        RET_IF(run_gemm(c, p, s));
+    }
+    return 0;
+}
+
+int mtts_speaker_embedding(mtts_ctx* c, int table, const int64_t* d_ids, int B, float* d_out, void* stream) {
+    RET_IF(check_ready(c));
+    const Vec& v = table == 0 ? c->enc.spk_enc : c->enc.spk_dur;
+    HIP_OK(launch_embedding(d_ids, W(c, v.off), B, c->cfg.spk_emb_dim, 1.0f, nullptr, d_out, c->cfg.spk_emb_dim, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mtts_durations(const float* d_logw, const float* d_x_mask, float scale_correction, float length_scale, int B, int Tx,
+                   float* d_durations, int32_t* d_cum, int64_t* d_y_fine_lengths, void* stream) {
+    HIP_OK(launch_durations(d_logw, d_x_mask, scale_correction, length_scale, B, Tx, d_durations, d_cum, d_y_fine_lengths,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_y_fine_lengths, int B, int n_feats, int Tx, int T_pad,
+                    float* d_mu_y, float* d_y_mask, int64_t* d_y_lengths, void* stream) {
+    HIP_OK(launch_align_pool(d_mu_x, d_cum, d_y_fine_lengths, B, n_feats, Tx, T_pad, d_mu_y, d_y_mask, d_y_lengths,
+                             static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ single kernels
+int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps) {
+    return (int64_t)round_up(N, GEMM_BN) * ntaps * round_up(C, GEMM_BK) * (int64_t)sizeof(float);
+}
+
+int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride, int T_out,
+                  const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_w, void* d_wpacked,
+                  const float* d_bias, int N, int act, const float* d_p0, const float* d_p1, const float* d_res, int ldr,
+                  const float* d_out_mask, float out_scale, float* d_out, int ldc, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
+    HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));
+    GemmArgs a;
+    a.a0 = d_a; a.lda0 = lda; a.c0 = C; a.ktap = round_up(C, GEMM_BK); a.ntaps = ntaps;
+    for (int j = 0; j < ntaps; ++j) a.tap_off[j] = h_tap_off ? h_tap_off[j] : 0;
+    a.in_stride = in_stride; a.B = B; a.T_in = T_in; a.T_out = T_out;
+    a.a_mask = d_a_mask; a.a_mean = d_a_mean; a.a_rstd = d_a_rstd;
+    a.w = static_cast<const float*>(d_wpacked); a.bias = d_bias; a.N = N; a.act = act; a.p0 = d_p0; a.p1 = d_p1;
+    a.res = d_res; a.ldr = ldr; a.out_mask = d_out_mask; a.out_scale = out_scale; a.out = d_out; a.ldc = ldc;
+    a.out_T = T_out; a.out_stride = 1; a.out_off = 0;
+    HIP_OK(launch_gemm(a, s));
+    return 0;
+}
+
+int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode, float* d_out,
+                       void* stream) {
+    AttnArgs a;
+    a.qkv = d_qkv; a.mask = d_mask; a.out = d_out; a.B = B; a.T = T; a.H = H; a.D = D; a.scale = scale; a.mask_mode = mask_mode;
+    HIP_OK(launch_attention(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream) {
+    HIP_OK(launch_row_stats(d_x, M, C, ld, eps, d_mean, d_rstd, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G) { return (int64_t)B * gn_chunks(T) * G * 2 * (int64_t)sizeof(float); }
+
+int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_beta, const float* d_mask, int B, int T, int C, int G,
+                        float eps, float* d_out, void* d_scratch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_OK(launch_gn_partial(d_y, B, T, C, G, static_cast<float*>(d_scratch), s));
+    GnApplyArgs a;
+    a.y = d_y; a.partial = static_cast<const float*>(d_scratch); a.gamma = d_gamma; a.beta = d_beta; a.mask = d_mask;
+    a.out = d_out; a.B = B; a.T = T; a.C = C; a.G = G; a.eps = eps;
+    HIP_OK(launch_gn_apply(a, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+int mtts_prof_enable(mtts_ctx* c, int on) {
+    if (!c) { set_error("null context"); return -1; }
+    c->prof_on = on != 0;
+    return 0;
+}
+int mtts_prof_reset(mtts_ctx* c) {
+    if (!c) { set_error("null context"); return -1; }
+    c->prof.clear();
+    c->ev_used = 0;
+    return 0;
+}
+int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double* flops) {
+    if (!c) { set_error("null context"); return -1; }
+    int64_t n = 0;
+    double t = 0, f = 0;
+    if (!c->prof.empty()) HIP_OK(hipEventSynchronize(c->prof.back().e1));
+    for (const ProfRec& r : c->prof) {
+        if (r.klass != klass) continue;
+        float el = 0.f;
+        HIP_OK(hipEventElapsedTime(&el, r.e0, r.e1));
+        t += el;
+        f += r.flops;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    return 0;
+}
+
+}  // extern "C"

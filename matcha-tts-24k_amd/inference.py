@@ -1,0 +1,236 @@
+"""Drop-in for the reference's ``matcha.inference`` module (reference matcha/inference.py) on MI355X.
+
+Same public names and call signatures -- ``load_matcha``, ``load_vocoder``, ``pipeline``, ``process_text``,
+``to_waveform``, ``MatchaTTSInfer.synthesise``, ``VOICES`` and the constants -- so that the reference's
+``matcha/cli.py`` and ``matcha/server.py`` keep working when their import is pointed here.
+The arithmetic of ``synthesise`` runs in libmtts_hip.so; there is no CPU path (only the ``debug=True`` extras and
+the two-term voice mix use a few PyTorch elementwise ops on device tensors, as the reference does).
+
+Extensions (backwards compatible): ``x`` may hold B > 1 utterances and ``speaker`` may be a LongTensor[B]
+(the reference builds a batch-1 speaker embedding and fails for B > 1, inference.py:118-121); ``synthesise``
+accepts ``z=`` (explicit noise) for parity checks against the CPU reference stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .hparams import N_VOCAB, PathHParams, from_reference_kwargs
+from .modules import Runtime, build_trees
+
+# Voice table of the shipped model: id, language, per-speaker duration scale correction (reference inference.py:16-32).
+VOICES = [
+    {"id": str(i), "lang": lang, "gender": gender, "name": name, "scale_correction": sc}
+    for i, (lang, gender, name, sc) in enumerate([
+        ("en-us", "male", "Kai", 1.08), ("en-us", "female", "Jane", 1.05), ("en-us", "female", "Aria", 1.05),
+        ("en-us", "female", "Bella", 1.03), ("en-gb", "male", "Brian", 1.08), ("en-gb", "male", "Arthur", 1.08),
+        ("en-us", "female", "Nicole", 1.05), ("ro", "male", "Emil", 1.04), ("fr-fr", "female", "Denise", 1.05),
+        ("fr-fr", "male", "Henri", 1.03), ("en-us", "male", "Matthew", 1.06), ("en-us", "male", "Lewis", 1.08),
+        ("en-us", "male", "Michael", 1.03), ("it", "female", "Isabella", 1.07), ("it", "male", "Marcello", 1.07),
+    ])
+]
+
+SAMPLE_RATE = 24000
+STD_RES_HOP_LENGTH = 256
+HIGH_RES_HOP_LENGTH = 128
+DEFAULT_ODE_SOLVER = "midpoint"
+DEFAULT_NUM_STEPS = 4
+DEVICE = torch.device("cuda")
+
+
+def fix_len_compatibility(length: int, num_downsamplings_in_unet: int = 1) -> int:
+    """ceil(length / 2^n) * 2^n (reference utils/model.py:15-21)."""
+    f = 2 ** num_downsamplings_in_unet
+    return int(math.ceil(int(length) / f) * f)
+
+
+class MatchaTTSInfer(nn.Module):
+    """Inference model: speaker tables + text encoder + CFM decoder (reference inference.py:44-183)."""
+
+    def __init__(self, n_spks, n_feats, encoder, decoder, cfm, data_statistics, spk_emb_dim, **_):
+        super().__init__()
+        hp = from_reference_kwargs(n_spks, n_feats, encoder, decoder, cfm, data_statistics, spk_emb_dim)
+        self._init_from_hparams(hp)
+
+    @classmethod
+    def from_hparams(cls, hp: PathHParams) -> "MatchaTTSInfer":
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self._init_from_hparams(hp)
+        return self
+
+    def _init_from_hparams(self, hp: PathHParams) -> None:
+        object.__setattr__(self, "hp", hp)
+        object.__setattr__(self, "_rt", Runtime(hp, self))
+        build_trees(hp, self, self._rt)
+        with torch.no_grad():
+            self.mel_mean.fill_(hp.mel_mean)
+            self.mel_std.fill_(hp.mel_std)
+
+    # ---- parameter changes invalidate the packed device image
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items() if "rope." not in k}
+        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._rt.dirty = True
+        return out
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._rt.dirty = True
+        return r
+
+    @property
+    def hip(self):
+        return self._rt.ready()
+
+    # ---- reference inference.py:57-76
+    def mix_speakers(self, speaker_mix):
+        dev = next(self.parameters()).device
+        mixed_enc = mixed_dur = None
+        hip = self._rt.ready()
+        for spk_id, weight in speaker_mix:
+            ids = torch.tensor([spk_id], device=dev, dtype=torch.long)
+            e_enc, e_dur = hip.speaker_embedding(0, ids), hip.speaker_embedding(1, ids)
+            mixed_enc = weight * e_enc if mixed_enc is None else mixed_enc + weight * e_enc
+            mixed_dur = weight * e_dur if mixed_dur is None else mixed_dur + weight * e_dur
+        return mixed_enc, mixed_dur
+
+    @torch.inference_mode()
+    def synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
+                   debug=False, z: Optional[torch.Tensor] = None):
+        """Text ids -> mel (reference inference.py:78-183).  Returns ``{"mel": [B, n_feats, T_valid_max]}`` (+ the
+        reference's debug tensors when ``debug``)."""
+        hip = self._rt.ready()
+        dev = x.device
+        B = x.shape[0]
+        if voice_mix is not None:
+            e_enc, e_dur = self.mix_speakers(voice_mix)
+        else:
+            ids = torch.as_tensor(speaker, dtype=torch.long, device=dev).reshape(-1)
+            e_enc, e_dur = hip.speaker_embedding(0, ids), hip.speaker_embedding(1, ids)
+        if e_enc.shape[0] not in (1, B):
+            raise ValueError("speaker must be an int or a LongTensor with one id per utterance")
+
+        mu_x, logw, x_mask = self.encoder(x, x_lengths, e_enc, e_dur)
+        durations, cum, y_fine_lengths = hip.durations(logw, x_mask, scale_correction, length_scale)
+        # the one host sync of the path, as in the reference (utils/model.py:19: .item())
+        max_fine = int(y_fine_lengths.max().item())
+        t_pad = fix_len_compatibility(max_fine)
+        mu_y, y_mask, y_lengths = hip.align_pool(mu_x, cum, y_fine_lengths, t_pad)
+        y_max_length = max((max_fine + 1) // 2, 1)
+
+        mel = self.decoder(mu_y, y_mask, n_timesteps, z=z, t_out=y_max_length, out_scale=self._rt.mel_std,
+                           out_shift=self._rt.mel_mean)
+        if not debug:
+            return {"mel": mel}
+        encoder_mel = mu_y[:, :, :y_max_length] * self._rt.mel_std + self._rt.mel_mean
+        raw = ((torch.exp(logw) - 2) * x_mask).squeeze(1)
+        return {"mel": mel, "encoder_mel": encoder_mel, "phoneme_durations": durations, "raw_phoneme_durations": raw,
+                "mel_lengths": y_lengths, "mu_y": mu_y, "y_mask": y_mask, "logw": logw, "mu_x": mu_x}
+
+
+def _plain(obj):
+    """OmegaConf containers -> plain python, when omegaconf is importable (it is not on the GPU box)."""
+    try:
+        from omegaconf import OmegaConf  # type: ignore
+        if OmegaConf.is_config(obj):
+            return OmegaConf.to_container(obj, resolve=True)
+    except Exception:
+        pass
+    return obj
+
+
+def load_matcha(model_name, checkpoint_path):
+    """reference inference.py:186-197: Lightning checkpoint with ``hyper_parameters`` + ``state_dict``."""
+    print(f"[!] Loading {model_name}!")
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    hparams = dict(_plain(ckpt["hyper_parameters"]))
+    hparams.pop("optimizer", None)
+    hparams.pop("scheduler", None)
+    model = MatchaTTSInfer(**hparams)
+    model.load_state_dict(ckpt["state_dict"], strict=False)
+    model = model.to(DEVICE).eval()
+    print(f"[+] {model_name} loaded!")
+    return model
+
+
+def process_text(text: str, language: str):
+    """reference inference.py:212-220.  The phonemizer (eSpeak + NeMo) is a CPU front end outside this package; it is
+    taken from the reference's ``matcha.text`` when that package is installed."""
+    try:
+        from matcha.text.phonemizers import multilingual_phonemizer  # type: ignore
+    except Exception as e:  # pragma: no cover - depends on the host installation
+        raise RuntimeError("process_text needs the reference's matcha.text phonemizer (eSpeak/NeMo); "
+                           "feed phoneme ids to synthesise() directly otherwise") from e
+    import re
+    emphasized = re.sub(r"(?<![?!])\?(?![?!])", "??", text)
+    separated, ids = multilingual_phonemizer(emphasized, language)
+    x = torch.tensor(ids, dtype=torch.long, device=DEVICE)[None]
+    x_lengths = torch.tensor([x.shape[-1]], dtype=torch.long, device=DEVICE)
+    return {"x_orig": text, "x": x, "x_lengths": x_lengths, "x_phones": "".join(separated), "x_phone_ids": ids}
+
+
+def load_vocoder(vocoder_name):
+    """reference inference.py:223-231.  The Vocos head is SURVEY section 8f item 1 (next); until it is built the
+    reference's own vocoder object is used when its package is installed."""
+    if vocoder_name != "vocos":
+        raise NotImplementedError(f"Vocoder {vocoder_name} not implemented!")
+    try:
+        from matcha.vocos24k.vocos_wrapper import load_model  # type: ignore
+    except Exception as e:  # pragma: no cover
+        raise NotImplementedError("the Vocos-24k head is not part of this package yet (SURVEY 8f-1) and the "
+                                  "reference's vocos wrapper is not installed") from e
+    return load_model(DEVICE)
+
+
+def to_waveform(mel, vocoder):
+    """reference inference.py:260-265."""
+    audio = vocoder(mel)
+    max_abs = audio.abs().max()
+    if max_abs > 1.0:
+        audio = audio / max_abs * 0.95
+    return audio.cpu().squeeze()
+
+
+def trim_trailing_silence(audio, silence_threshold_db=-60.0):
+    """reference inference.py:268-287: drop trailing 10 ms windows whose RMS is under the threshold."""
+    win = int(0.01 * SAMPLE_RATE)
+    thr = 10.0 ** (silence_threshold_db / 20.0)
+    n = audio.shape[-1]
+    end = n
+    while end > win:
+        seg = audio[..., end - win:end]
+        if float(torch.sqrt(torch.mean(seg.float() ** 2))) > thr:
+            break
+        end -= win
+    return audio[..., :end]
+
+
+@torch.inference_mode()
+def pipeline(model, vocoder, text, speaker=0, voice_mix=None, n_timesteps=DEFAULT_NUM_STEPS, scale_correction=1.0,
+             length_scale=1.0, debug=False):
+    """reference inference.py:233-257."""
+    primary = voice_mix[0][0] if voice_mix is not None else speaker
+    language = next(v["lang"] for v in VOICES if v["id"] == str(primary))
+    tp = process_text(text, language)
+    out = model.synthesise(tp["x"], tp["x_lengths"], n_timesteps=n_timesteps, speaker=speaker, voice_mix=voice_mix,
+                           scale_correction=scale_correction, length_scale=length_scale, debug=debug)
+    if not debug:
+        return trim_trailing_silence(to_waveform(out["mel"], vocoder))
+    durs = out["phoneme_durations"].squeeze(0).tolist()
+    raws = out["raw_phoneme_durations"].squeeze(0).tolist()
+    pairs = list(zip(tp["x_phones"], raws, durs))
+    return (trim_trailing_silence(to_waveform(out["mel"], vocoder)), to_waveform(out["encoder_mel"], vocoder), pairs)
+
+
+def convert_to_mp3(waveform):  # pragma: no cover - post-waveform codec, out of the path's scope
+    from matcha.utils.mp3_converter import encode_mp3  # type: ignore
+    import numpy as np
+    return encode_mp3((waveform.numpy() * 32767).astype(np.int16), SAMPLE_RATE)
+
+
+def convert_to_opus_ogg(waveform):  # pragma: no cover - post-waveform codec, out of the path's scope
+    raise NotImplementedError("OGG/Opus encoding (PyAV) is outside the synthesis path; use the reference's encoder")

@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's model objects for the synthesis path.
+
+The reference classes (TextEncoder text_encoder.py:319, Decoder decoder.py:202, CFM flow_matching.py:110)
+are ``nn.Module`` trees whose ``forward`` runs PyTorch ops.  Here the trees only *hold* the parameters, under
+exactly the reference's state-dict names (generated from ``synthetic.state_dict_spec``), and ``forward`` calls
+the HIP library through one shared ``HipModel``.  There is no PyTorch arithmetic and no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ._hip import HipModel
+from .hparams import PathHParams
+from .synthetic import state_dict_spec
+
+_BUFFER_KINDS = ("mel_mean", "mel_std")
+
+
+class ParamTree(nn.Module):
+    """A bare container node; children and parameters are attached by dotted state-dict key."""
+
+    def node(self, name: str) -> "ParamTree":
+        if name not in self._modules:
+            self.add_module(name, ParamTree())
+        return self._modules[name]
+
+    def attach(self, key: str, shape, kind: str) -> None:
+        parts = key.split(".")
+        n = self
+        for p in parts[:-1]:
+            n = n.node(p)
+        t = torch.zeros(shape, dtype=torch.float32)
+        if kind in _BUFFER_KINDS:
+            n.register_buffer(parts[-1], t)
+        else:
+            n.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+class Runtime:
+    """Shared by every module of one model: the HIP context and the lazily refreshed packed weights."""
+
+    def __init__(self, hp: PathHParams, owner: nn.Module):
+        self.hp = hp
+        self.owner = owner          # root module whose state_dict is the source of truth
+        self.hip: Optional[HipModel] = None
+        self.dirty = True
+        self.mel_mean, self.mel_std = hp.mel_mean, hp.mel_std
+
+    def ready(self) -> HipModel:
+        if self.hip is None:
+            self.hip = HipModel(self.hp)
+        if self.dirty:
+            p = next(self.owner.parameters())
+            if not p.is_cuda:
+                raise RuntimeError("matcha-tts-24k_amd: the model must be on a HIP device (model.to('cuda')); "
+                                   "there is no CPU path")
+            sd = self.owner.state_dict()
+            self.hip.load_state_dict(sd, p.device)
+            # denormalisation constants come from the checkpoint's buffers (reference inference.py:54-55,172)
+            self.mel_mean, self.mel_std = float(sd["mel_mean"]), float(sd["mel_std"])
+            self.dirty = False
+        return self.hip
+
+
+class _PathModule(ParamTree):
+    """Base of the callable modules: keeps a (non-registered) handle on the shared runtime."""
+
+    def _bind(self, rt: Runtime) -> None:
+        object.__setattr__(self, "_rt", rt)
+
+
+class TextEncoder(_PathModule):
+    """``encoder(x, x_lengths, e_enc, e_dur) -> (mu_x, logw, x_mask)`` -- reference text_encoder.py:375-406."""
+
+    def forward(self, x, x_lengths, speaker_embedding_enc, speaker_embedding_dur):
+        if x.shape[1] > 4000:   # the reference's RoPE cache limit (text_encoder.py:138,164)
+            raise AssertionError("Phonetic representation too long, exceeds RoPE cache size 4000")
+        return self._rt.ready().text_encoder(x, x_lengths, speaker_embedding_enc, speaker_embedding_dur)
+
+
+class Estimator(_PathModule):
+    """``estimator(x, mask, mu, t) -> velocity`` -- reference decoder.py:359-426."""
+
+    def forward(self, x, mask, mu, t):
+        return self._rt.ready().decoder_forward(x, mask, mu, float(t))
+
+
+class CFM(nn.Module):
+    """``decoder(mu, mask, n_timesteps)`` / ``.solve(x, t_span, mu, mask)`` -- reference flow_matching.py:25-63,110-117.
+
+    ``solver`` is a plain attribute that callers overwrite per request (reference cli.py:94, server.py:43,109).
+    ``estimator`` may be re-assigned with a ``torch.compile`` wrapper (reference server.py:47); the wrapper is
+    unwrapped, because the estimator already is a fixed sequence of HIP launches.
+    """
+
+    def __init__(self, hp: PathHParams, rt: Runtime):
+        super().__init__()
+        self.n_feats = 2 * hp.n_feats
+        self.solver = hp.solver
+        self.sigma_min = hp.sigma_min
+        self.use_mu_prior = hp.use_mu_prior
+        object.__setattr__(self, "_rt", rt)
+        self.estimator = Estimator()
+        self.estimator._bind(rt)
+
+    def __setattr__(self, name, value):
+        if name == "estimator" and hasattr(value, "_orig_mod"):
+            value = value._orig_mod
+        super().__setattr__(name, value)
+
+    def noise(self, like: torch.Tensor) -> torch.Tensor:
+        """The seed-42 draw of flow_matching.py:43-55 on ``like``'s device generator."""
+        g = torch.Generator(device=like.device)
+        g.manual_seed(42)
+        return torch.randn(like.shape, generator=g, dtype=like.dtype, device=like.device)
+
+    @torch.inference_mode()
+    def forward(self, mu, mask, n_timesteps, z: Optional[torch.Tensor] = None, t_out: Optional[int] = None,
+                out_scale: float = 1.0, out_shift: float = 0.0):
+        """``z``: optional explicit noise (e.g. the CPU-generator stream for parity with the CPU reference)."""
+        if z is None:
+            z = self.noise(mu)
+        t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
+        return self._rt.ready().cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
+                                          out_scale=out_scale, out_shift=out_shift)
+
+    def solve(self, x, t_span, mu, mask):
+        return self._rt.ready().cfm_solve(x, mu, mask, t_span, self.solver)
+
+    def solve_euler(self, x, t_span, mu, mask):
+        """Upstream Matcha-TTS name for the same loop with the euler solver."""
+        return self._rt.ready().cfm_solve(x, mu, mask, t_span, "euler")
+
+
+def build_trees(hp: PathHParams, root: nn.Module, rt: Runtime) -> None:
+    """Attach every parameter of the path to ``root`` under the reference's names."""
+    enc, cfm, est = TextEncoder(), CFM(hp, rt), None
+    enc._bind(rt)
+    est = cfm.estimator
+    root.encoder = enc
+    root.decoder = cfm
+    root.speaker_embeddings_enc = ParamTree()
+    root.speaker_embeddings_dur = ParamTree()
+    for key, shape, kind in state_dict_spec(hp):
+        if key.startswith("encoder."):
+            enc.attach(key[len("encoder."):], shape, kind)
+        elif key.startswith("decoder.estimator."):
+            est.attach(key[len("decoder.estimator."):], shape, kind)
+        elif key.startswith("speaker_embeddings_enc."):
+            root.speaker_embeddings_enc.attach(key.split(".", 1)[1], shape, kind)
+        elif key.startswith("speaker_embeddings_dur."):
+            root.speaker_embeddings_dur.attach(key.split(".", 1)[1], shape, kind)
+        elif kind in _BUFFER_KINDS:
+            root.register_buffer(key, torch.zeros(shape, dtype=torch.float32))
+        else:
+            raise KeyError(key)

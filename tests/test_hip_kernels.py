@@ -1,0 +1,142 @@
+"""GPU parity of the single HIP kernels, called through the C ABI (include/mtts.h), against fp64 PyTorch on the CPU.
+
+fp32-input MFMA is an exact fp32 FMA chain, so the only difference from a CPU fp32 GEMM is summation order;
+tolerances are a few fp32 ulps of the accumulated magnitude."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import sub
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("a HIP device is required for -m gpu tests (no CPU fallback exists)")
+    return sub("_hip")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(out, ref, tol):
+    out = out.detach().cpu().double()
+    err = (out - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    assert err <= tol * max(mag, 1.0), f"max abs err {err:.3e} (ref magnitude {mag:.3e})"
+
+
+def conv_ref(a, w, bias, B, T, pad, stride=1):
+    """a [B*T, C] channels-last -> conv1d -> [B*T_out, N] (fp64)."""
+    C = a.shape[1]
+    x = a.double().view(B, T, C).transpose(1, 2)
+    y = F.conv1d(x, w.double(), None if bias is None else bias.double(), stride=stride, padding=pad)
+    return y.transpose(1, 2).reshape(-1, w.shape[0])
+
+
+@pytest.mark.parametrize("B,T,C,N", [(3, 100, 384, 384), (2, 77, 200, 100), (1, 5, 64, 1), (4, 160, 1536, 384), (1, 130, 96, 288)])
+def test_linear_bias_residual(hip, B, T, C, N):
+    a, w, b, r = rnd(B * T, C, seed=1), rnd(N, C, seed=2, scale=C ** -0.5), rnd(N, seed=3), rnd(B * T, N, seed=4)
+    ref = F.linear(a.double(), w.double(), b.double()) + r.double()
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, res=r.cuda())
+    close(out, ref, 2e-6 * math.sqrt(C))
+
+
+def test_identity_asymmetric(hip):
+    """A = I with an asymmetric W catches a transposed accumulator map."""
+    n = 128
+    a = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).view(n, n) / 1000.0
+    out = hip.gemm_f32(a.cuda(), w.cuda(), None, B=1, T_in=n)
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("k,C,N,B,T", [(3, 64, 96, 2, 77), (5, 96, 160, 3, 50), (3, 200, 384, 2, 130), (5, 1152, 288, 1, 128)])
+def test_conv_same_with_mask(hip, k, C, N, B, T):
+    a, w, b = rnd(B * T, C, seed=5), rnd(N, C, k, seed=6, scale=(C * k) ** -0.5), rnd(N, seed=7)
+    lens = torch.tensor([T - 7 * i for i in range(B)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().reshape(-1)
+    ref = conv_ref(a * mask[:, None], w, b, B, T, k // 2)
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda())
+    close(out, ref, 2e-6 * math.sqrt(C * k))
+    # the same with relu / silu and an output mask
+    for act, fn in ((1, torch.relu), (2, F.silu)):
+        out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), act=act, out_mask=mask.cuda())
+        close(out, fn(ref) * mask[:, None].double(), 2e-6 * math.sqrt(C * k))
+
+
+def test_conv_stride2(hip):
+    B, T, C, N = 2, 50, 64, 64
+    a, w, b = rnd(B * T, C, seed=8), rnd(N, C, 3, seed=9, scale=(3 * C) ** -0.5), rnd(N, seed=10)
+    ref = conv_ref(a, w, b, B, T, 1, stride=2)
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, T_out=25, in_stride=2)
+    close(out, ref, 2e-5)
+
+
+def test_layernorm_prologue_and_snake(hip):
+    B, T, C, N = 2, 90, 384, 1536
+    a = rnd(B * T, C, seed=11) * 2 + 0.3
+    w, b = rnd(N, C, seed=12, scale=C ** -0.5), rnd(N, seed=13)
+    alpha, beta = rnd(N, seed=14, scale=0.2), rnd(N, seed=15, scale=0.2)
+    mean, rstd = hip.row_stats(a.cuda())
+    ad = a.double()
+    mu = ad.mean(1)
+    var = ((ad - mu[:, None]) ** 2).mean(1)
+    close(mean, mu, 1e-6)
+    close(rstd, 1 / torch.sqrt(var + 1e-5), 1e-6)
+    h = F.linear((ad - mu[:, None]) / torch.sqrt(var + 1e-5)[:, None], w.double(), b.double())
+    ae, ib = torch.exp(alpha), 1.0 / (torch.exp(beta) + 1e-9)
+    ref = h + ib.double() * torch.sin(h * ae.double()) ** 2
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd, act=3, p0=ae.cuda(), p1=ib.cuda())
+    close(out, ref, 1e-5)
+
+
+@pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0)])
+def test_attention(hip, oracle, B, T, H, D, mode):
+    qkv = rnd(B * T, 3 * H * D, seed=20)
+    lens = torch.tensor([T - 11 * i for i in range(B)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()
+    q, k, v = [z.view(B, T, H, D).transpose(1, 2).double() for z in qkv.split(H * D, dim=1)]
+    scale = 1.0 / math.sqrt(D)
+    if mode == 0:
+        ref = oracle.sdpa_reference(q, k, v, mask.double().view(B, 1, 1, T).expand(B, H, 1, T), scale)
+    else:
+        ref = oracle.sdpa_reference(q, k, v, (mask[:, None, :, None] * mask[:, None, None, :]).bool(), scale)
+    ref = ref.transpose(1, 2).reshape(B * T, H * D)
+    out = hip.attention_f32(qkv.cuda(), mask.reshape(-1).cuda(), B, T, H, D, scale, mode)
+    if mode == 1:   # padded query rows are "don't care" (zeroed downstream by x_mask)
+        keep = mask.reshape(-1).bool()
+        out, ref = out.cpu()[keep], ref[keep]
+    close(out, ref, 5e-6)
+
+
+def test_attention_forced_rescale(hip, oracle):
+    """One key per tile dominates so that the running max jumps at every tile boundary (online-softmax rescale path)."""
+    B, T, H, D = 1, 256, 1, 64
+    qkv = rnd(B * T, 3 * D, seed=21, scale=0.5)
+    q, k, v = qkv[:, :D].clone(), qkv[:, D:2 * D].clone(), qkv[:, 2 * D:].clone()
+    for tile in range(4):
+        k[tile * 64 + 13] = q[5] * (4.0 + 3.0 * tile)
+    qkv = torch.cat([q, k, v], 1)
+    mask = torch.ones(B * T)
+    ref = oracle.sdpa_reference(q.double()[None, None], k.double()[None, None], v.double()[None, None], None, 0.125)[0, 0]
+    out = hip.attention_f32(qkv.cuda(), mask.cuda(), B, T, H, D, 0.125, 0)
+    close(out, ref, 5e-6)
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 100, 384), (3, 24, 64), (1, 33, 384)])
+def test_groupnorm_mish(hip, B, T, C):
+    y = rnd(B * T, C, seed=30) * 1.5 + 0.2
+    g, b = 1 + 0.1 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
+    lens = torch.tensor([T - 5 * i for i in range(B)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().reshape(-1)
+    x = y.double().view(B, T, C).transpose(1, 2)
+    ref = (F.mish(F.group_norm(x, 8, g.double(), b.double(), eps=1e-5)) * mask.view(B, 1, T).double()).transpose(1, 2).reshape(-1, C)
+    out = hip.groupnorm_mish(y.cuda(), g.cuda(), b.cuda(), mask.cuda(), B, T)
+    close(out, ref, 3e-6)
