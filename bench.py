@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: valid mel-frames/s of end-to-end synthesise() (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of synthetic input: ids on the device -> text encoder ->
+durations -> alignment -> CFM decoder ODE solve (euler, n_timesteps=10) -> denormalised mel on the device.
+Workload at N=1 = BASELINE.json configs[1]: batch 32 random phoneme sequences of 128 tokens, n_spks=1, fp32,
+prod v20 architecture with random-init weights (no checkpoints exist offline), 5 fine frames per token, i.e.
+T_pad = 640 decoder frames and 320 valid mel frames per utterance, strict reference padding.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): utterances shard data-parallel, every rank synthesises its
+own 32 utterances (weak scaling) and the finished mels are all-gathered over RCCL inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-events]
+prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch
+import torch.distributed as dist
+
+PKG = "matcha-tts-24k_amd"
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BATCH, N_TOKENS, N_STEPS_ODE, SOLVER = 32, 128, 10, "euler"
+
+
+def algorithmic_flops(hp, batch, t_pad, tx, nfe):
+    """GEMM/conv/attention MACs x 2 (30.08 GFLOP per NFE per utterance at T=640; encoder+DP 4.08)."""
+    C = hp.decoder.channels[0]
+    T = t_pad
+
+    def R(i, o):
+        return 4 * i * o + 3 * o * o
+
+    def TB(tl):
+        return 4 * C * C + 8 * C * C + 2 * tl * C
+
+    dec = 2 * (R(2 * hp.n_feats, C) * T + R(C, C) * 3 * T / 2 + R(2 * C, C) * 3 * T / 2 + 4 * TB(T) * T + 8 * TB(T / 2) * T / 2
+               + 3 * C * C * T / 2 + 3 * C * C * T / 2 + 4 * C * C * T / 2 + 3 * C * C * T + 3 * C * C * T + C * hp.n_feats * T)
+    e = hp.encoder
+    H = e.n_channels + hp.spk_emb_dim
+    enc = 2 * tx * (e.prenet_layers * e.prenet_kernel_size * e.n_channels ** 2 + e.n_channels ** 2
+                    + e.n_layers * (4 * H * H + 2 * tx * H + 2 * e.kernel_size * H * e.filter_channels)
+                    + H * e.n_channels + e.n_channels * hp.n_feats
+                    + e.dp_kernel_size * (H * e.dp_filter_channels + (e.dp_n_layers - 1) * e.dp_filter_channels ** 2) + e.dp_filter_channels)
+    return batch * (nfe * dec + enc)
+
+
+def cpu_baseline(hp, sd, synthetic, budget_s=12.0):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import matcha_oracle as O
+    threads = torch.get_num_threads()
+    b = 2
+    x, x_len, _ = synthetic.make_inputs(hp, b, N_TOKENS, seed=1234)
+    frames, reps = 0, 0
+    with torch.inference_mode():
+        O.synthesise(sd, hp, x[:1], x_len[:1], 1, speaker=0, solver=SOLVER)   # warm the thread pool
+        t0 = time.perf_counter()
+        while True:
+            out = O.synthesise(sd, hp, x, x_len, N_STEPS_ODE, speaker=0, solver=SOLVER)
+            frames += int(out["mel_lengths"].sum())
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s and reps >= 2:
+                break
+    return {"value": round(frames / el, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x synthesise(B={b}, Tx={N_TOKENS}, {SOLVER}/{N_STEPS_ODE}) = {frames} valid frames in {el:.1f}s, "
+                      f"oracle/matcha_oracle.py, torch CPU fp32, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event pass (roofline = null)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    hparams = importlib.import_module(PKG + ".hparams")
+    synthetic = importlib.import_module(PKG + ".synthetic")
+    inference = importlib.import_module(PKG + ".inference")
+    dp = importlib.import_module(PKG + ".dp")
+
+    hp = hparams.prod_v20(n_spks=1)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    model = inference.MatchaTTSInfer(**hp.as_reference_kwargs())
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.decoder.solver = SOLVER
+
+    # this rank's shard of the global batch (different utterances per rank; same per-rank work: weak scaling)
+    x_all, len_all, _ = synthetic.make_inputs(hp, BATCH * world, N_TOKENS, seed=1234)
+    sl = dp.shard_slice(BATCH * world, world, rank)
+    x, x_len = x_all[sl].to(dev), len_all[sl].to(dev)
+
+    def step():
+        mel = model.synthesise(x, x_len, n_timesteps=N_STEPS_ODE, speaker=0)["mel"]
+        if world > 1:
+            mel = dp.all_gather_mels(mel, world)
+        return mel
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mel = step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    valid_per_utt = mel.shape[-1]
+    frames = valid_per_utt * BATCH * world * args.steps
+    t_pad = 2 * valid_per_utt
+
+    roofline = None
+    if rank == 0 and not args.no_events:
+        # same steps again with a HIP event pair around every kernel launch, recorded on the launch stream
+        hip = model.hip
+        hip.prof_enable(True)
+        hip.prof_reset()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.synthesise(x, x_len, n_timesteps=N_STEPS_ODE, speaker=0)
+        torch.cuda.synchronize()
+        p_el = time.perf_counter() - p0
+        n_g, ms_g, fl_g = hip.prof_read(0)
+        n_a, ms_a, fl_a = hip.prof_read(1)
+        n_e, ms_e, _ = hip.prof_read(2)
+        hip.prof_enable(False)
+        hip.prof_reset()
+        achieved = fl_g / (ms_g * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA GEMM / implicit conv1d, all instantiations)",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n_g // args.steps, "avg_launch_us": round(ms_g * 1e3 / max(n_g, 1), 2),
+            "gflop_per_launch": round(fl_g / max(n_g, 1) / 1e9, 3),
+            "gemm_ms_per_step": round(ms_g / args.steps, 3),
+            "attention": {"tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2), "ms_per_step": round(ms_a / args.steps, 3),
+                          "launches_per_step": n_a // args.steps},
+            "elementwise_ms_per_step": round(ms_e / args.steps, 3), "elementwise_launches_per_step": n_e // args.steps,
+            "whole_path_tflops": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE) * args.steps / el / 1e12, 2),
+            "ms_per_step_with_events": round(p_el / args.steps * 1e3, 2),
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(hp, sd, synthetic)
+
+    if rank == 0:
+        line = {
+            "metric": "mel-frames/s (100-bin, 24 kHz) end-to-end synthesise(), n_timesteps=10",
+            "value": round(frames / el, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
+                                   "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "
+                                   "(reference 2x padding), noise from the device seed-42 generator",
+                       "per_gpu_batch": BATCH, "global_batch": BATCH * world, "n_tokens": N_TOKENS, "parallelism": f"dp{world}",
+                       "n_feats": hp.n_feats, "note": "the reference fork uses 100 mel bins (Vocos-24k), not 80"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

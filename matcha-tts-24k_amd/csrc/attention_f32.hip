@@ -68,36 +68,34 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs p)
     const int sd = (tid & 3) * 4;
     f32x4 rk[4], rv[4];
     float rbias = 0.f;
+    bool r_in = false;
+    // all loads unconditional (clamped addresses), zeroing deferred to the LDS write: nothing waits inside the fetch
     auto fetch = [&](int k0) {
         const int key = k0 + srow;
-        const bool in = key < p.T;
+        r_in = key < p.T;
+        const size_t row = rowbase + (r_in ? key : 0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             const int d = sd + 16 * c;
-            if (in && d < p.D) {
-                kv = *reinterpret_cast<const f32x4*>(kptr + (rowbase + key) * ld + d);
-                vv = *reinterpret_cast<const f32x4*>(vptr + (rowbase + key) * ld + d);
-            }
-            rk[c] = kv;
-            rv[c] = vv;
+            const int dd = d < p.D ? d : 0;
+            rk[c] = *reinterpret_cast<const f32x4*>(kptr + row * ld + dd);
+            rv[c] = *reinterpret_cast<const f32x4*>(vptr + row * ld + dd);
+        }
+        rbias = p.mask ? p.mask[row] : 1.0f;
+    };
+    auto stage = [&]() {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = r_in && (sd + 16 * c) < p.D;
+            *reinterpret_cast<f32x4*>(Ks + srow * AT_S + sd + 16 * c) = ok ? rk[c] : zero;
+            *reinterpret_cast<f32x4*>(Vs + srow * AT_S + sd + 16 * c) = ok ? rv[c] : zero;
         }
         if ((tid & 3) == 0) {
             float bv = ninf;
-            if (in) {
-                const float mv = p.mask ? p.mask[rowbase + key] : 1.0f;
-                bv = (p.mask_mode == 0) ? mv : (mv != 0.f ? 0.f : ninf);
-            }
-            rbias = bv;
+            if (r_in) bv = (p.mask_mode == 0) ? rbias : (rbias != 0.f ? 0.f : ninf);
+            Bs[srow] = bv;
         }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            *reinterpret_cast<f32x4*>(Ks + srow * AT_S + sd + 16 * c) = rk[c];
-            *reinterpret_cast<f32x4*>(Vs + srow * AT_S + sd + 16 * c) = rv[c];
-        }
-        if ((tid & 3) == 0) Bs[srow] = rbias;
     };
 
     const int ntiles = (p.T + AT_K - 1) / AT_K;

@@ -11,7 +11,7 @@
 // (pack([x, mu]) decoder.py:371, skip connections decoder.py:410) is two K segments read from two tensors.
 //
 // Tiling (one 256-thread workgroup = 4 waves, 2x2):
-//   block tile 128x128x32, wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs)
+//   block tile 128x128x32 (or 64x128x32 for small grids), wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs)
 //   global -> registers (prefetch of tile k+1 issued before the MFMAs of tile k) -> LDS, two LDS buffers, one barrier per k-step
 //   LDS rows are K-contiguous, stride 36 floats: the 16-byte fragment reads (ds_read_b128) and tile writes are conflict free
 //   inside a group of 8 k the MFMA kk consumes k = {kk, 4+kk}: lane half h owns k = 4h..4h+3, i.e. one ds_read_b128
@@ -19,14 +19,17 @@
 // fp32-input MFMA is an exact fp32 FMA chain (157 TFLOP/s peak): results differ from a CPU GEMM only by summation order.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace mtts {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int LDS_STRIDE = GEMM_BK + 4;                              // 36 floats = 144 B (9 x 16 B)
-constexpr int TILE_FLOATS = (GEMM_BM + GEMM_BN) * LDS_STRIDE;        // one (A,B) stage
-constexpr int GEMM_LDS_BYTES = 2 * TILE_FLOATS * 4;                  // 73,728 B -> 2 workgroups per CU
+// one (A,B) stage of a BM x 128 block tile; two stages: BM=128 -> 73,728 B, BM=64 -> 55,296 B (2 workgroups per CU)
+constexpr int tile_floats(int BM) { return (BM + GEMM_BN) * LDS_STRIDE; }
+constexpr int gemm_lds_bytes(int BM) { return 2 * tile_floats(BM) * 4; }
 
 __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
     switch (act) {
@@ -40,8 +43,13 @@ __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1)
     }
 }
 
-template <bool A_MASK, bool A_NORM>
+// BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2), used when the 128-row grid would leave
+// CUs with a single resident workgroup (nothing to overlap its staging with).
+template <int BM, bool A_MASK, bool A_NORM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
+    constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along M
+    constexpr int AR = BM / 32;                 // A rows staged per thread
+    constexpr int TILE_FLOATS = tile_floats(BM);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,15 +67,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int m0 = (swz / n_tiles) * GEMM_BM;
+    const int m0 = (swz / n_tiles) * BM;
     const int n0 = (swz % n_tiles) * GEMM_BN;
 
     // ---- per-thread staging coordinates: 4 rows x one float4 of K for A and for W
     const int lrow = tid >> 3;
     const int lq = (tid & 7) * 4;
-    int arow_base[4], at[4];
+    int arow_base[AR], at[AR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AR; ++i) {
         const int m = m0 + lrow + 32 * i;
         if (m < M) {
             const int b = m / p.T_out;
@@ -80,27 +88,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     }
     const float* wrow = p.w + (size_t)(n0 + lrow) * Kp + lq;
 
-    f32x4 ra[4], rb[4];
-    int ld_tap = 0, ld_c = 0;   // (tap, channel) of the next tile to fetch
+    // Tile fetch: every load is issued unconditionally (out-of-range rows read row 0 and are zeroed later), no load
+    // depends on another load's result, and the mask / LayerNorm transform is deferred to the LDS write -- so the 8-20
+    // loads of tile k+1 are all in flight under the MFMAs of tile k.
+    f32x4 ra[AR], rb[4];
+    float r_mask[AR], r_mean[AR], r_rstd[AR];
+    bool r_ok[AR];
+    int ld_tap = 0, ld_c = 0;   // (tap, channel) of the next tile to fetch; a 32-wide K chunk never straddles segments
     auto fetch = [&]() {
-        const int c = ld_c + lq;
-        const float* src;
-        int ld, cc;
-        bool cvalid;
-        if (c < p.c0) { src = p.a0; ld = p.lda0; cc = c; cvalid = true; }
-        else { src = p.a1; ld = p.lda1; cc = c - p.c0; cvalid = cc < p.c1; }
+        const bool seg1 = p.a1 != nullptr && ld_c >= p.c0;          // wave-uniform
+        const float* src = seg1 ? p.a1 : p.a0;
+        const int ld = seg1 ? p.lda1 : p.lda0;
+        const int cc = (seg1 ? ld_c - p.c0 : ld_c) + lq;
+        const bool cvalid = cc < (seg1 ? p.c1 : p.c0);
         const int off = p.tap_off[ld_tap];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AR; ++i) {
             const int tin = at[i] + off;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cvalid && tin >= 0 && tin < p.T_in) {
-                const int row = arow_base[i] + tin;
-                v = *reinterpret_cast<const f32x4*>(src + (size_t)row * ld + cc);
-                if (A_NORM) { const float mu = p.a_mean[row], rs = p.a_rstd[row]; v = (v - mu) * rs; }
-                if (A_MASK) { v *= p.a_mask[row]; }
-            }
-            ra[i] = v;
+            const bool ok = cvalid && (unsigned)tin < (unsigned)p.T_in;
+            const int row = ok ? arow_base[i] + tin : 0;
+            ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)row * ld + (ok ? cc : 0));
+            r_ok[i] = ok;
+            if (A_NORM) { r_mean[i] = p.a_mean[row]; r_rstd[i] = p.a_rstd[row]; }
+            if (A_MASK) { r_mask[i] = p.a_mask[row]; }
         }
         const float* wp = wrow + ld_tap * p.ktap + ld_c;
 #pragma unroll
@@ -110,17 +120,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     };
     auto stage = [&](int buf) {
         float* As = lds + buf * TILE_FLOATS;
-        float* Bs = As + GEMM_BM * LDS_STRIDE;
+        float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_STRIDE + lq) = ra[i];
-            *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lq) = rb[i];
+        for (int i = 0; i < AR; ++i) {
+            f32x4 v = ra[i];
+            if (A_NORM) v = (v - r_mean[i]) * r_rstd[i];
+            if (A_MASK) v *= r_mask[i];
+            if (!r_ok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_STRIDE + lq) = v;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lq) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -135,21 +150,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) fetch();
-        const float* Aw = lds + (kt & 1) * TILE_FLOATS + (wm * 64) * LDS_STRIDE + frag_off;
-        const float* Bw = lds + (kt & 1) * TILE_FLOATS + (GEMM_BM + wn * 64) * LDS_STRIDE + frag_off;
+        const float* Aw = lds + (kt & 1) * TILE_FLOATS + (wm * (BM / 2)) * LDS_STRIDE + frag_off;
+        const float* Bw = lds + (kt & 1) * TILE_FLOATS + (BM + wn * 64) * LDS_STRIDE + frag_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Aw + 8 * g);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Aw + 32 * LDS_STRIDE + 8 * g);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bw + 8 * g);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bw + 32 * LDS_STRIDE + 8 * g);
+            f32x4 a[MI], b[2];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDS_STRIDE + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDS_STRIDE + 8 * g);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
         }
         if (more) stage((kt + 1) & 1);
         __syncthreads();
@@ -159,9 +175,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     // Each wave parks its 64x64 tile in LDS (free after the last barrier) and re-reads it as float4 rows, so that the
     // epilogue math runs on 4 consecutive columns per lane and every store instruction writes whole 256-byte row pieces.
     constexpr int CS = 68;   // row stride of the parked tile (floats)
-    float* Cw = lds + wave * (64 * CS);
+    float* Cw = lds + wave * ((BM / 2) * CS);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -181,9 +197,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             if (p.act == ACT_SNAKE) { s0[e] = p.p0[nc + e]; s1[e] = p.p1[nc + e]; }
         }
     }
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < BM / 8; ++it) {
         const int rl = it * 4 + (lane >> 4);
-        const int m = m0 + wm * 64 + rl;
+        const int m = m0 + wm * (BM / 2) + rl;
         if (m >= M || nc >= p.N) continue;
         int orow = m;
         if (!plain_rows) {
@@ -213,20 +229,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     }
 }
 
-template <bool A_MASK, bool A_NORM>
+template <int BM, bool A_MASK, bool A_NORM>
 static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_f32_kernel<A_MASK, A_NORM>;
+    auto kern = gemm_f32_kernel<BM, A_MASK, A_NORM>;
+    constexpr int lds_bytes = gemm_lds_bytes(BM);
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         configured = true;
     }
     const int M = a.B * a.T_out;
-    const int grid = ((M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, a);
+    const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int BM>
+static hipError_t launch_bm(const GemmArgs& a, hipStream_t s) {
+    const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr;
+    if (mk && nm) return launch_variant<BM, true, true>(a, s);
+    if (mk) return launch_variant<BM, true, false>(a, s);
+    if (nm) return launch_variant<BM, false, true>(a, s);
+    return launch_variant<BM, false, false>(a, s);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -240,11 +265,13 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.lda0 < a.c0 || (a.a1 && a.lda1 < a.c1)) return hipErrorInvalidValue;
     if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
-    const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr;
-    if (mk && nm) return launch_variant<true, true>(a, s);
-    if (mk) return launch_variant<true, false>(a, s);
-    if (nm) return launch_variant<false, true>(a, s);
-    return launch_variant<false, false>(a, s);
+    // 128-row tiles unless that grid cannot give most of the 256 CUs two resident workgroups
+    const int M = a.B * a.T_out;
+    const int tiles128 = ((M + 127) / 128) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();   // A/B runs only
+    const int force = a.force_bm ? a.force_bm : env_bm;
+    if (force == 64 || (force == 0 && tiles128 < 384)) return launch_bm<64>(a, s);
+    return launch_bm<128>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

@@ -45,6 +45,7 @@ struct GemmArgs {
     float* out = nullptr;
     int ldc = 0;
     int out_T = 1, out_stride = 1, out_off = 0;   // output row = b*out_T + t*out_stride + out_off
+    int force_bm = 0;                 // 0 = choose the block tile height from the grid size; 64 / 128 = force (tests)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {

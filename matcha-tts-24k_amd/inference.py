@@ -100,9 +100,13 @@ class MatchaTTSInfer(nn.Module):
 
     @torch.inference_mode()
     def synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
-                   debug=False, z: Optional[torch.Tensor] = None):
+                   debug=False, z=None, sync_max=None):
         """Text ids -> mel (reference inference.py:78-183).  Returns ``{"mel": [B, n_feats, T_valid_max]}`` (+ the
-        reference's debug tensors when ``debug``)."""
+        reference's debug tensors when ``debug``).
+
+        ``z``: explicit noise [B, n_feats, T_pad], or a callable ``T_pad -> noise``; default = the device seed-42
+        generator like the reference.  ``sync_max``: callable mapping this process's maximum fine length to the
+        batch-wide one (data-parallel shards must pad like the whole batch, see dp.py)."""
         hip = self._rt.ready()
         dev = x.device
         B = x.shape[0]
@@ -118,14 +122,18 @@ class MatchaTTSInfer(nn.Module):
         durations, cum, y_fine_lengths = hip.durations(logw, x_mask, scale_correction, length_scale)
         # the one host sync of the path, as in the reference (utils/model.py:19: .item())
         max_fine = int(y_fine_lengths.max().item())
+        if sync_max is not None:
+            max_fine = int(sync_max(max_fine))
         t_pad = fix_len_compatibility(max_fine)
+        if callable(z):
+            z = z(t_pad)
         mu_y, y_mask, y_lengths = hip.align_pool(mu_x, cum, y_fine_lengths, t_pad)
         y_max_length = max((max_fine + 1) // 2, 1)
 
         mel = self.decoder(mu_y, y_mask, n_timesteps, z=z, t_out=y_max_length, out_scale=self._rt.mel_std,
                            out_shift=self._rt.mel_mean)
         if not debug:
-            return {"mel": mel}
+            return {"mel": mel, "mel_lengths": y_lengths}
         encoder_mel = mu_y[:, :, :y_max_length] * self._rt.mel_std + self._rt.mel_mean
         raw = ((torch.exp(logw) - 2) * x_mask).squeeze(1)
         return {"mel": mel, "encoder_mel": encoder_mel, "phoneme_durations": durations, "raw_phoneme_durations": raw,

@@ -48,6 +48,21 @@ def test_linear_bias_residual(hip, B, T, C, N):
     close(out, ref, 2e-6 * math.sqrt(C))
 
 
+def test_large_grid_uses_128_row_tiles(hip):
+    """M x N big enough for the 128x128 block tile (small problems above run on the 64x128 variant)."""
+    B, T, C, N = 8, 1000, 96, 1152
+    a, w, b = rnd(B * T, C, seed=41), rnd(N, C, seed=42, scale=C ** -0.5), rnd(N, seed=43)
+    ref = F.linear(a.double(), w.double(), b.double())
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T)
+    close(out, ref, 2e-5)
+    # implicit conv on the same tile shape, ragged mask
+    w3 = rnd(N, C, 3, seed=44, scale=(3 * C) ** -0.5)
+    lens = torch.tensor([T - 13 * i for i in range(B)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().reshape(-1)
+    out = hip.gemm_f32(a.cuda(), w3.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda())
+    close(out, conv_ref(a * mask[:, None], w3, b, B, T, 1), 2e-5)
+
+
 def test_identity_asymmetric(hip):
     """A = I with an asymmetric W catches a transposed accumulator map."""
     n = 128
