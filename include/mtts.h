@@ -124,7 +124,8 @@ int mtts_cfm_solve(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const fl
 /* C[M,N] = epilogue(prologue(A)[M,K] * W[N,K]^T): the fp32-MFMA GEMM every Linear/Conv1d of the path runs on.
  * A is [B*T_in, lda] row major (channels last).  ntaps>1 makes it an implicit 1-D convolution:
  * K = ntaps*C, output row (b,t) reads input rows t*in_stride + tap_off[tap].  W is the *unpacked* torch weight:
- * Linear [N,C] or Conv1d [N,C,ntaps]; it is packed into d_wpacked (mtts_gemm_packed_bytes) on the stream first.
+ * Linear [N,C] or Conv1d [N,C,ntaps]; it is packed into d_wpacked (mtts_gemm_packed_bytes) on the stream first
+ * (d_w = NULL: d_wpacked already holds the packed panel from an earlier call).
  * act: 0 none, 1 relu, 2 silu, 3 SnakeBeta with d_p0 = exp(alpha)[N], d_p1 = 1/(exp(beta)+1e-9)[N]
  * (reference transformer.py:61-77).  Epilogue: c = act(acc + bias); c *= out_mask[row]; c = c*out_scale + res[row][n].
  * All optional pointers may be NULL. */

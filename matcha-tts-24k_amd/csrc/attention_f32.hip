@@ -20,13 +20,19 @@ namespace mtts {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int AT_Q = 128;     // queries per workgroup
+constexpr int AT_QW = 32;     // queries per wave (one 32-column MFMA tile)
 constexpr int AT_K = 64;      // keys per tile
 constexpr int AT_D = 64;      // padded head dim
 constexpr int AT_S = 68;      // LDS row stride (floats): 17 x 16 B, conflict-free b128 row reads
 constexpr float NEG_BIG = -1e30f;
 
-__global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs p) {
+// NW waves per workgroup = NW*32 queries.  NW = 4 for long sequences; NW = 2 when T is short enough that 128-query
+// blocks would leave the last block mostly empty or the grid under one round (e.g. T = 320: 3 blocks of 128 waste 17 %).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
+    constexpr int NT = 64 * NW;                   // threads
+    constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
+    constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
     __shared__ __attribute__((aligned(16))) float Ks[AT_K * AT_S];
     __shared__ __attribute__((aligned(16))) float Vs[AT_K * AT_S];
     __shared__ __attribute__((aligned(16))) float Bs[AT_K];
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * AT_Q + wave * 32;
+    const int q0 = blockIdx.x * (NW * AT_QW) + wave * AT_QW;
     const int ld = 3 * p.H * p.D;
     const size_t rowbase = (size_t)b * p.T;
     const float* qptr = p.qkv + head * p.D;
@@ -63,38 +69,45 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs p)
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
-    // ---- staging: thread -> key row tid>>2, float4 columns (tid&3)*4 + 16c: 4 lanes read 64 contiguous bytes per load
-    const int srow = tid >> 2;           // 0..63
+    // ---- staging: thread -> key row (tid>>2) + SROWS*pass, float4 columns (tid&3)*4 + 16c: 4 lanes read 64 contiguous bytes
+    const int srow = tid >> 2;
     const int sd = (tid & 3) * 4;
-    f32x4 rk[4], rv[4];
-    float rbias = 0.f;
-    bool r_in = false;
+    f32x4 rk[SP][4], rv[SP][4];
+    float rbias[SP];
+    bool r_in[SP];
     // all loads unconditional (clamped addresses), zeroing deferred to the LDS write: nothing waits inside the fetch
     auto fetch = [&](int k0) {
-        const int key = k0 + srow;
-        r_in = key < p.T;
-        const size_t row = rowbase + (r_in ? key : 0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int d = sd + 16 * c;
-            const int dd = d < p.D ? d : 0;
-            rk[c] = *reinterpret_cast<const f32x4*>(kptr + row * ld + dd);
-            rv[c] = *reinterpret_cast<const f32x4*>(vptr + row * ld + dd);
+        for (int sp = 0; sp < SP; ++sp) {
+            const int key = k0 + srow + SROWS * sp;
+            r_in[sp] = key < p.T;
+            const size_t row = rowbase + (r_in[sp] ? key : 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int d = sd + 16 * c;
+                const int dd = d < p.D ? d : 0;
+                rk[sp][c] = *reinterpret_cast<const f32x4*>(kptr + row * ld + dd);
+                rv[sp][c] = *reinterpret_cast<const f32x4*>(vptr + row * ld + dd);
+            }
+            rbias[sp] = p.mask ? p.mask[row] : 1.0f;
         }
-        rbias = p.mask ? p.mask[row] : 1.0f;
     };
     auto stage = [&]() {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool ok = r_in && (sd + 16 * c) < p.D;
-            *reinterpret_cast<f32x4*>(Ks + srow * AT_S + sd + 16 * c) = ok ? rk[c] : zero;
-            *reinterpret_cast<f32x4*>(Vs + srow * AT_S + sd + 16 * c) = ok ? rv[c] : zero;
-        }
-        if ((tid & 3) == 0) {
-            float bv = ninf;
-            if (r_in) bv = (p.mask_mode == 0) ? rbias : (rbias != 0.f ? 0.f : ninf);
-            Bs[srow] = bv;
+        for (int sp = 0; sp < SP; ++sp) {
+            const int r = srow + SROWS * sp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = r_in[sp] && (sd + 16 * c) < p.D;
+                *reinterpret_cast<f32x4*>(Ks + r * AT_S + sd + 16 * c) = ok ? rk[sp][c] : zero;
+                *reinterpret_cast<f32x4*>(Vs + r * AT_S + sd + 16 * c) = ok ? rv[sp][c] : zero;
+            }
+            if ((tid & 3) == 0) {
+                float bv = ninf;
+                if (r_in[sp]) bv = (p.mask_mode == 0) ? rbias[sp] : (rbias[sp] != 0.f ? 0.f : ninf);
+                Bs[r] = bv;
+            }
         }
     };
 
@@ -188,8 +201,15 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (!a.qkv || !a.out || a.B <= 0 || a.T <= 0 || a.H <= 0) return hipErrorInvalidValue;
     if (a.D <= 0 || a.D > AT_D || (a.D & 3)) return hipErrorInvalidValue;
     if (a.mask_mode == 1 && !a.mask) return hipErrorInvalidValue;
-    dim3 grid((a.T + AT_Q - 1) / AT_Q, a.H, a.B);
-    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, s, a);
+    // 128-query blocks when they fill at least ~1.5 rounds of the chip without much tail waste, else 64-query blocks
+    const int b128 = (a.T + 127) / 128, b64 = (a.T + 63) / 64;
+    const long blocks128 = (long)b128 * a.H * a.B;
+    const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
+    if (blocks128 >= 768 && waste128 < 0.1) {
+        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(b128, a.H, a.B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(attention_f32_kernel<2>, dim3(b64, a.H, a.B), dim3(128), 0, s, a);
+    }
     return hipGetLastError();
 }
 

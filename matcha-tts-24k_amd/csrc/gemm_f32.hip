@@ -265,12 +265,19 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.lda0 < a.c0 || (a.a1 && a.lda1 < a.c1)) return hipErrorInvalidValue;
     if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
-    // 128-row tiles unless that grid cannot give most of the 256 CUs two resident workgroups
+    // Block-tile height: 256 CUs x 2 resident workgroups = 512 slots per round; pick the height whose grid wastes the
+    // least of its last round (e.g. M=10240, N=1152: 720 tiles of 128 rows fill 70 % of two rounds, 1440 tiles of 64
+    // rows fill 94 % of three).  The 64-row tile has half the A-fragment reuse, hence the small handicap.
     const int M = a.B * a.T_out;
-    const int tiles128 = ((M + 127) / 128) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    const int nt = (a.N + GEMM_BN - 1) / GEMM_BN;
+    auto fill = [&](int bm) {
+        const int tiles = ((M + bm - 1) / bm) * nt;
+        const int rounds = (tiles + 511) / 512;
+        return (double)tiles / (rounds * 512.0) * ((double)M / (((M + bm - 1) / bm) * bm));
+    };
     static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();   // A/B runs only
     const int force = a.force_bm ? a.force_bm : env_bm;
-    if (force == 64 || (force == 0 && tiles128 < 384)) return launch_bm<64>(a, s);
+    if (force == 64 || (force == 0 && 0.97 * fill(64) > fill(128))) return launch_bm<64>(a, s);
     return launch_bm<128>(a, s);
 }
 

@@ -879,7 +879,7 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
                   const float* d_out_mask, float out_scale, float* d_out, int ldc, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
-    HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));
+    if (d_w) HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));   // NULL: d_wpacked already packed
     GemmArgs a;
     a.a0 = d_a; a.lda0 = lda; a.c0 = C; a.ktap = round_up(C, GEMM_BK); a.ntaps = ntaps;
     for (int j = 0; j < ntaps; ++j) a.tap_off[j] = h_tap_off ? h_tap_off[j] : 0;

@@ -112,7 +112,8 @@ def test_layernorm_prologue_and_snake(hip):
     close(out, ref, 1e-5)
 
 
-@pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0)])
+@pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0),
+                                           (8, 1024, 12, 64, 0), (8, 1000, 12, 48, 1)])   # the last two run the 128-query block variant
 def test_attention(hip, oracle, B, T, H, D, mode):
     qkv = rnd(B * T, 3 * H * D, seed=20)
     lens = torch.tensor([T - 11 * i for i in range(B)])
