@@ -56,11 +56,29 @@ def algorithmic_flops(hp, batch, t_pad, tx, nfe):
     return batch * (nfe * dec + enc)
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot collect PMC
+    counters itself, so the committed summary of the latest run under profiles/ is reported (null if absent)."""
+    f = ROOT / "profiles" / "pmc_traffic_latest.json"
+    if not f.exists():
+        return None
+    try:
+        return json.loads(f.read_text())["gemm_hbm_mb_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(hp, sd, synthetic, budget_s=12.0):
     """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import matcha_oracle as O
-    threads = torch.get_num_threads()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    threads = min(avail, 16)            # a 1-GPU box's CPU share is 16 cores; oversubscribing torch's pool is slower
+    torch.set_num_threads(threads)
     b = 2
     x, x_len, _ = synthetic.make_inputs(hp, b, N_TOKENS, seed=1234)
     frames, reps = 0, 0
@@ -157,16 +175,17 @@ def main():
             model.synthesise(x, x_len, n_timesteps=N_STEPS_ODE, speaker=0)
         torch.cuda.synchronize()
         p_el = time.perf_counter() - p0
-        n_g, ms_g, fl_g = hip.prof_read(0)
-        n_a, ms_a, fl_a = hip.prof_read(1)
-        n_e, ms_e, _ = hip.prof_read(2)
+        n_g, ms_g, fl_g, by_g = hip.prof_read(0)
+        n_a, ms_a, fl_a, by_a = hip.prof_read(1)
+        n_e, ms_e, _, _ = hip.prof_read(2)
         hip.prof_enable(False)
         hip.prof_reset()
         achieved = fl_g / (ms_g * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA GEMM / implicit conv1d, all instantiations)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+            "algorithmic_mb_per_launch": round(by_g / max(n_g, 1) / 1e6, 2),
             "launches_per_step": n_g // args.steps, "avg_launch_us": round(ms_g * 1e3 / max(n_g, 1), 2),
             "gflop_per_launch": round(fl_g / max(n_g, 1) / 1e9, 3),
             "gemm_ms_per_step": round(ms_g / args.steps, 3),

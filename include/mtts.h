@@ -157,8 +157,9 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
  * Classes: 0 gemm, 1 attention, 2 norm/activation/elementwise. */
 int mtts_prof_enable(mtts_ctx* ctx, int on);
 int mtts_prof_reset(mtts_ctx* ctx);
-/* Synchronises the recorded events; returns launches, summed milliseconds and algorithmic FLOPs of a class. */
-int mtts_prof_read(mtts_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops);
+/* Synchronises the recorded events; returns launches, summed milliseconds, algorithmic FLOPs and compulsory HBM
+ * bytes (every operand and result element once) of a class. */
+int mtts_prof_read(mtts_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,7 @@ def load() -> C.CDLL:
         "mtts_groupnorm_mish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
-        "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -296,9 +296,9 @@ class HipModel:
         check(self.lib.mtts_prof_reset(self.ctx))
 
     def prof_read(self, klass: int):
-        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-        check(self.lib.mtts_prof_read(self.ctx, klass, C.byref(n), C.byref(ms), C.byref(fl)))
-        return n.value, ms.value, fl.value
+        n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        check(self.lib.mtts_prof_read(self.ctx, klass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return n.value, ms.value, fl.value, by.value
 
 
 # ---------------------------------------------------------------------- single kernels (used by the parity tests)

@@ -5,8 +5,7 @@
 //            softmax(q k^T / sqrt(D) + bias) v with an ADDITIVE float key bias (mask value 1.0 valid / 0.0 padded)
 //   encoder: F.scaled_dot_product_attention with a boolean query*key mask (reference text_encoder.py:228-235,306)
 //
-// Work split: grid (ceil(T/128), H, B); a 256-thread workgroup owns 128 queries of one (batch, head), each of its
-// 4 waves 32 of them.  Keys/values stream through LDS in tiles of 64 (global -> registers prefetch -> LDS).
+// Work split: one workgroup per (batch, head, block of 128 or 64 queries), each of its 4 or 2 waves 32 of them.  Keys/values stream through LDS in tiles of 64 (global -> registers prefetch -> LDS).
 // Both products run on v_mfma_f32_32x32x2_f32 in the "transposed" orientation so that the query sits on the lane:
 //   S^T[key][q] = K[key][:] . Q[q][:]     A = K fragment (LDS, ds_read_b128), B = Q fragment (registers, loaded once)
 //   O^T[d][q]  += V^T[d][key] . P^T[key][q]   A = V column (LDS, ds_read_b32), B = the S^T accumulator itself
@@ -39,8 +38,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * (NW * AT_QW) + wave * AT_QW;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
+    // (batch, head, q-block) so the q-blocks that re-read one head's K/V hit the same L2 (measured before this remap:
+    // 331 MB fetched per launch at B=32, T=640 against 94 MB of q|k|v).
+    const int qblocks = (p.T + NW * AT_QW - 1) / (NW * AT_QW);
+    int swz;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int qb = swz % qblocks, head = (swz / qblocks) % p.H, b = swz / (qblocks * p.H);
+    const int q0 = qb * (NW * AT_QW) + wave * AT_QW;
     const int ld = 3 * p.H * p.D;
     const size_t rowbase = (size_t)b * p.T;
     const float* qptr = p.qkv + head * p.D;
@@ -206,9 +215,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const long blocks128 = (long)b128 * a.H * a.B;
     const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
     if (blocks128 >= 768 && waste128 < 0.1) {
-        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(b128, a.H, a.B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(attention_f32_kernel<2>, dim3(b64, a.H, a.B), dim3(128), 0, s, a);
+        hipLaunchKernelGGL(attention_f32_kernel<2>, dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
     }
     return hipGetLastError();
 }

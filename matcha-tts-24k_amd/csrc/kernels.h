@@ -51,6 +51,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
 }
+// compulsory HBM bytes of one launch: every input row, weight, residual and output element once
+static inline double gemm_bytes(const GemmArgs& a) {
+    const double M = double(a.B) * a.T_out, Min = double(a.B) * a.T_in;
+    return 4.0 * (Min * (a.c0 + a.c1) + double(a.N) * a.ntaps * (a.c0 + a.c1) + M * a.N * (a.res ? 2.0 : 1.0));
+}
 
 // Pack a torch weight into the GEMM panel layout [Np][ntaps*ktap] (host side).
 //   kind 0: Linear [N, C]   kind 1: Conv1d [N, C, ntaps]   kind 2: ConvTranspose1d [C, N, kT] taking taps `tsel[0..ntaps)`
@@ -69,6 +74,7 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
+static inline double attn_bytes(const AttnArgs& a) { return 4.0 * double(a.B) * a.T * 4.0 * a.H * a.D; }
 
 // ---- normalisation / activation / glue (norm_glue.hip)
 hipError_t launch_row_stats(const float* x, int M, int C, int ld, float eps, float* mean, float* rstd, hipStream_t s);

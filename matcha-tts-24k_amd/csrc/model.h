@@ -57,7 +57,7 @@ struct EncW {
     Panel dp_proj;
 };
 
-struct ProfRec { hipEvent_t e0, e1; int klass; double flops; };
+struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; };
 
 }  // namespace mtts
 

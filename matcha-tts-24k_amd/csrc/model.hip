@@ -26,14 +26,14 @@ const char* get_error() { return g_err.c_str(); }
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ profiling wrappers
-static int prof_begin(mtts_ctx* c, int klass, double flops, hipStream_t s) {
+static int prof_begin(mtts_ctx* c, int klass, double flops, double bytes, hipStream_t s) {
     if (!c || !c->prof_on) return 0;
     while (c->ev_pool.size() < c->ev_used + 2) {
         hipEvent_t e;
         HIP_OK(hipEventCreate(&e));
         c->ev_pool.push_back(e);
     }
-    ProfRec r{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], klass, flops};
+    ProfRec r{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], klass, flops, bytes};
     c->ev_used += 2;
     HIP_OK(hipEventRecord(r.e0, s));
     c->prof.push_back(r);
@@ -45,18 +45,20 @@ static int prof_end(mtts_ctx* c, hipStream_t s) {
     return 0;
 }
 #define LAUNCH(ctx, klass, flops, stream, call)  \
+    LAUNCHB(ctx, klass, flops, 0.0, stream, call)
+#define LAUNCHB(ctx, klass, flops, bytes, stream, call)  \
     do {                                         \
-        RET_IF(prof_begin(ctx, klass, flops, stream)); \
+        RET_IF(prof_begin(ctx, klass, flops, bytes, stream)); \
         HIP_OK(call);                            \
         RET_IF(prof_end(ctx, stream));           \
     } while (0)
 
 static int run_gemm(mtts_ctx* c, const GemmArgs& a, hipStream_t s) {
-    LAUNCH(c, 0, gemm_flops(a), s, launch_gemm(a, s));
+    LAUNCHB(c, 0, gemm_flops(a), gemm_bytes(a), s, launch_gemm(a, s));
     return 0;
 }
 static int run_attn(mtts_ctx* c, const AttnArgs& a, hipStream_t s) {
-    LAUNCH(c, 1, attn_flops(a), s, launch_attention(a, s));
+    LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
 
@@ -930,10 +932,10 @@ int mtts_prof_reset(mtts_ctx* c) {
     c->ev_used = 0;
     return 0;
 }
-int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double* flops) {
+int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double* flops, double* bytes) {
     if (!c) { set_error("null context"); return -1; }
     int64_t n = 0;
-    double t = 0, f = 0;
+    double t = 0, f = 0, by = 0;
     if (!c->prof.empty()) HIP_OK(hipEventSynchronize(c->prof.back().e1));
     for (const ProfRec& r : c->prof) {
         if (r.klass != klass) continue;
@@ -941,11 +943,13 @@ int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double
         HIP_OK(hipEventElapsedTime(&el, r.e0, r.e1));
         t += el;
         f += r.flops;
+        by += r.bytes;
         ++n;
     }
     if (launches) *launches = n;
     if (ms) *ms = t;
     if (flops) *flops = f;
+    if (bytes) *bytes = by;
     return 0;
 }
 
