@@ -98,13 +98,19 @@ def cpu_baseline(hp, sd, synthetic, budget_s=12.0):
 
 
 def main():
+    global BATCH, SOLVER, N_STEPS_ODE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event pass (roofline = null)")
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default 32 = BASELINE configs[1]; other values are labelled)")
+    ap.add_argument("--solver", default=SOLVER)
+    ap.add_argument("--n-timesteps", type=int, default=N_STEPS_ODE)
     args = ap.parse_args()
+    default_cfg = (args.batch, args.solver, args.n_timesteps) == (BATCH, SOLVER, N_STEPS_ODE)
+    BATCH, SOLVER, N_STEPS_ODE = args.batch, args.solver, args.n_timesteps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -192,7 +198,7 @@ def main():
             "attention": {"tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2), "ms_per_step": round(ms_a / args.steps, 3),
                           "launches_per_step": n_a // args.steps},
             "elementwise_ms_per_step": round(ms_e / args.steps, 3), "elementwise_launches_per_step": n_e // args.steps,
-            "whole_path_tflops": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE) * args.steps / el / 1e12, 2),
+            "whole_path_tflops": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE * {'euler': 1, 'midpoint': 2, 'rk4': 4}[SOLVER]) * args.steps / el / 1e12, 2),
             "ms_per_step_with_events": round(p_el / args.steps * 1e3, 2),
         }
 
@@ -206,7 +212,8 @@ def main():
             "value": round(frames / el, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
+            "config": {"workload": ("" if default_cfg else f"NON-DEFAULT batch={BATCH} {SOLVER}/{N_STEPS_ODE} variant of ") +
+                                   "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
                                    "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "
                                    "(reference 2x padding), noise from the device seed-42 generator",
                        "per_gpu_batch": BATCH, "global_batch": BATCH * world, "n_tokens": N_TOKENS, "parallelism": f"dp{world}",
