@@ -151,6 +151,22 @@ int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G);
 int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_beta, const float* d_mask, int B, int T,
                         int C, int G, float eps, float* d_out, void* d_scratch, void* stream);
 
+/* ---------------------------------------------------------------- Vocos-24k head */
+
+/* Vocos.decode -- reference matcha/vocos24k/vocos_wrapper.py:8-9 (third-party vocos package; architecture sizes from
+ * reference matcha/vocos24k/config.yaml:10-24).  mel [B, n_mels, T] -> audio [B, hop*(T-1)] (torch.istft, center=True).
+ * Tensors are registered under the vocos state-dict keys ("backbone.embed.weight", "backbone.convnext.0.dwconv.weight",
+ * "head.out.weight", ...) plus "aux.window" = the periodic hann window [n_fft]. */
+typedef struct mtts_vocos mtts_vocos;
+mtts_vocos* mtts_vocos_create(int n_mels, int dim, int intermediate_dim, int num_layers, int n_fft, int hop_length);
+void mtts_vocos_destroy(mtts_vocos* v);
+int mtts_vocos_set_tensor(mtts_vocos* v, const char* key, const float* h_data, int64_t numel);
+int64_t mtts_vocos_weights_bytes(mtts_vocos* v);
+int mtts_vocos_upload_weights(mtts_vocos* v, void* d_weights, int64_t bytes);
+int64_t mtts_vocos_workspace_bytes(mtts_vocos* v, int B, int T);
+int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_audio, void* d_ws, int64_t ws_bytes,
+                      void* stream);
+
 /* ---------------------------------------------------------------- measurement */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline line).

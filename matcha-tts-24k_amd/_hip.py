@@ -19,7 +19,7 @@ from .hparams import PathHParams
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmtts_hip.so"
-SOURCES = ["gemm_f32.hip", "attention_f32.hip", "norm_glue.hip", "model.hip"]
+SOURCES = ["gemm_f32.hip", "attention_f32.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
 HEADERS = [CSRC / "kernels.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
 SOLVERS = {"euler": 0, "midpoint": 1, "rk4": 2}
 
@@ -86,6 +86,13 @@ def load() -> C.CDLL:
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
         "mtts_groupnorm_mish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+        "mtts_vocos_create": (vp, [i32, i32, i32, i32, i32, i32]),
+        "mtts_vocos_destroy": (None, [vp]),
+        "mtts_vocos_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
+        "mtts_vocos_weights_bytes": (i64, [vp]),
+        "mtts_vocos_upload_weights": (i32, [vp, vp, i64]),
+        "mtts_vocos_workspace_bytes": (i64, [vp, i32, i32]),
+        "mtts_vocos_decode": (i32, [vp, vp, i32, i32, vp, vp, i64, vp]),
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
         "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

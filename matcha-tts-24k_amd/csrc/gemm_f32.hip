@@ -39,6 +39,7 @@ __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1)
             float s = sinf(c * p0);
             return c + p1 * (s * s);
         }
+        case ACT_GELU: return 0.5f * c * (1.0f + erff(c * 0.70710678118654752440f));   // exact GELU (vocos ConvNeXtBlock)
         default: return c;
     }
 }

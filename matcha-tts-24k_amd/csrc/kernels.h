@@ -9,11 +9,11 @@ namespace mtts {
 constexpr int GEMM_BM = 128;
 constexpr int GEMM_BN = 128;
 constexpr int GEMM_BK = 32;
-constexpr int MAX_TAPS = 5;
+constexpr int MAX_TAPS = 7;
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SNAKE = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SNAKE = 3, ACT_GELU = 4 };
 
 // C[M,N] = epi( pro(A)[M,K] . W[N,K]^T )   -- see gemm_f32.hip for the tiling.
 struct GemmArgs {
@@ -24,7 +24,7 @@ struct GemmArgs {
     int c0 = 0, c1 = 0;          // channels read from each segment (c0 % 32 == 0 whenever a1 != nullptr)
     int ktap = 0;                // padded K per tap = round_up(c0 + c1, 32)
     int ntaps = 1;
-    int tap_off[MAX_TAPS] = {0, 0, 0, 0, 0};
+    int tap_off[MAX_TAPS] = {0, 0, 0, 0, 0, 0, 0};
     int in_stride = 1;           // t_in = t_out * in_stride + tap_off[tap]
     int B = 1, T_in = 1, T_out = 1;   // M = B * T_out
     const float* a_mask = nullptr;    // [B*T_in]  multiply A rows
@@ -135,5 +135,14 @@ hipError_t launch_durations(const float* logw, const float* mask, float scale_co
 hipError_t launch_mask_down(const float* src, int B, int T_src, int stride, float* dst, int T_dst, hipStream_t s);
 hipError_t launch_align_pool(const float* mu_x, const int32_t* cum, const int64_t* yfl, int B, int nf, int Tx, int T_pad,
                              float* mu_y, float* y_mask, int64_t* y_len, hipStream_t s);
+
+// ---- Vocos head (vocos.hip)
+// y = LayerNorm_C(depthwise_conv_k7(x) + bias) * gamma + beta on channels-last rows [B*T, C]; w7 is [7][C]
+hipError_t launch_dwconv7_ln(const float* x, const float* w7, const float* bias, const float* gamma, const float* beta, float eps,
+                             int B, int T, int C, float* y, hipStream_t s);
+// in place on rows [M, ld]: (log-magnitude m_k, phase p_k) at columns (k, off + k) -> (Re, Im) = min(exp(m),clip) * (cos p, sin p)
+hipError_t launch_spec_polar(float* x, int M, int ld, int nbins, int off, float clip, hipStream_t s);
+// overlap-add of windowed frames [B*T, n_fft] (hop) with the squared-window envelope, centre trim: audio [B, hop*(T-1)]
+hipError_t launch_istft_ola(const float* frames, const float* window, int B, int T, int n_fft, int hop, float* audio, hipStream_t s);
 
 }  // namespace mtts

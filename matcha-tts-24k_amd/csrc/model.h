@@ -57,6 +57,13 @@ struct EncW {
     Panel dp_proj;
 };
 
+struct VocosW {
+    Panel embed, head, basis;
+    Vec norm_g, norm_b, fin_g, fin_b, window;
+    std::vector<Vec> dw_w, dw_b, ln_g, ln_b;
+    std::vector<Panel> pw1, pw2;
+};
+
 struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; };
 
 }  // namespace mtts
@@ -74,4 +81,13 @@ struct mtts_ctx {
     std::vector<mtts::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+};
+
+// Vocos-24k head: its own weight image and context (the reference loads it as a separate object,
+// reference matcha/inference.py:223-231).  `base` carries the tensor registry, the packed image and the profiler.
+struct mtts_vocos {
+    mtts_ctx base;
+    int n_mels = 100, dim = 512, inter = 1536, layers = 8, n_fft = 1024, hop = 256;
+    int ld_spec = 0, im_off = 0;     // head output row: [Re/logmag 0..n_fft/2 | pad | Im/phase at im_off.. | pad]
+    mtts::VocosW w;
 };

@@ -114,6 +114,18 @@ struct Packer {
                 const std::vector<float>* col_shift = nullptr) {
         return panel_multi({wkey}, {bkey}, kind, N, C, ntaps, kT, tsel, col_scale, col_shift);
     }
+    // a panel from explicit host data (rearranged / synthesised weights)
+    Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
+        Panel p;
+        p.N = N; p.C = C; p.ntaps = ntaps; p.ktap = round_up(C, GEMM_BK);
+        const int Np = round_up(N, GEMM_BN);
+        const size_t Kp = (size_t)ntaps * p.ktap;
+        p.w = alloc((size_t)Np * Kp);
+        p.b = alloc(Np);
+        pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w]);
+        if (bias) { p.has_bias = true; std::memcpy(&c->image[p.b], bias, N * sizeof(float)); }
+        return p;
+    }
     // several [N_i, C(,k)] tensors stacked along N into one panel (q|k|v, concatenated time MLPs)
     Panel panel_multi(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys, int kind, int N_each, int C,
                       int ntaps, int kT = 0, const int* tsel = nullptr, const std::vector<float>* col_scale = nullptr,
@@ -950,6 +962,191 @@ int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double
     if (ms) *ms = t;
     if (flops) *flops = f;
     if (bytes) *bytes = by;
+    return 0;
+}
+
+
+// ================================================================================================ Vocos head
+static int vocos_pack(mtts_vocos* v) {
+    mtts_ctx* c = &v->base;
+    c->image.clear();
+    Packer P(c);
+    VocosW& W = v->w;
+    W = VocosW();
+    const int C = v->dim, nb = v->n_fft / 2 + 1;
+    auto S = [](const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; };
+    W.embed = P.panel("backbone.embed.weight", "backbone.embed.bias", 1, C, v->n_mels, 7);
+    W.norm_g = P.vec("backbone.norm.weight", C);
+    W.norm_b = P.vec("backbone.norm.bias", C);
+    for (int i = 0; i < v->layers; ++i) {
+        const std::string p = S("backbone.convnext.", i, ".");
+        // depthwise weight [C,1,7] -> [7][C] so that a lane's 4 channels are one float4 per tap
+        const auto* dw = P.get(p + "dwconv.weight", (size_t)C * 7);
+        if (!dw) break;
+        Vec wv;
+        wv.off = P.alloc((size_t)7 * C);
+        wv.n = 7 * C;
+        for (int ch = 0; ch < C; ++ch)
+            for (int j = 0; j < 7; ++j) c->image[wv.off + (size_t)j * C + ch] = (*dw)[(size_t)ch * 7 + j];
+        W.dw_w.push_back(wv);
+        W.dw_b.push_back(P.vec(p + "dwconv.bias", C));
+        W.ln_g.push_back(P.vec(p + "norm.weight", C));
+        W.ln_b.push_back(P.vec(p + "norm.bias", C));
+        W.pw1.push_back(P.panel(p + "pwconv1.weight", p + "pwconv1.bias", 0, v->inter, C, 1));
+        // layer scale folded into pwconv2: gamma * (W x + b) = (gamma W) x + gamma b
+        const auto* w2 = P.get(p + "pwconv2.weight", (size_t)C * v->inter);
+        const auto* b2 = P.get(p + "pwconv2.bias", C);
+        const auto* gm = P.get(p + "gamma", C);
+        if (!w2 || !b2 || !gm) break;
+        std::vector<float> ws(w2->size()), bs(C);
+        for (int n = 0; n < C; ++n) {
+            for (int k = 0; k < v->inter; ++k) ws[(size_t)n * v->inter + k] = (*gm)[n] * (*w2)[(size_t)n * v->inter + k];
+            bs[n] = (*gm)[n] * (*b2)[n];
+        }
+        W.pw2.push_back(P.panel_from(ws.data(), bs.data(), 0, C, v->inter, 1));
+    }
+    W.fin_g = P.vec("backbone.final_layer_norm.weight", C);
+    W.fin_b = P.vec("backbone.final_layer_norm.bias", C);
+    // head: rows [log-magnitude 0..nb) | phase nb..2nb) re-spaced so that both halves start on a multiple of 4 columns
+    v->im_off = round_up(nb, 4);
+    v->ld_spec = round_up(v->im_off + nb, 4);
+    {
+        const auto* hw = P.get("head.out.weight", (size_t)2 * nb * C);
+        const auto* hb = P.get("head.out.bias", (size_t)2 * nb);
+        if (hw && hb) {
+            std::vector<float> ws((size_t)v->ld_spec * C, 0.f), bs(v->ld_spec, 0.f);
+            for (int r = 0; r < 2 * nb; ++r) {
+                const int dst = r < nb ? r : v->im_off + (r - nb);
+                std::memcpy(&ws[(size_t)dst * C], &(*hw)[(size_t)r * C], C * sizeof(float));
+                bs[dst] = (*hb)[r];
+            }
+            W.head = P.panel_from(ws.data(), bs.data(), 0, v->ld_spec, C, 1);
+        }
+    }
+    // inverse real DFT (torch.fft.irfft, norm "backward") times the synthesis window, as a [n_fft][ld_spec] matrix:
+    // frame[n] = w[n]/N * sum_k c_k (Re_k cos(2 pi k n / N) - Im_k sin(2 pi k n / N)), c_0 = c_{N/2} = 1, else 2
+    W.window = P.vec("aux.window", v->n_fft);
+    if (P.ok) {
+        const int N = v->n_fft;
+        std::vector<float> bm((size_t)N * v->ld_spec, 0.f);
+        const float* win = &c->image[W.window.off];
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < nb; ++k) {
+                const double ck = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+                const double ang = two_pi * (double)(((long long)k * n) % N) / (double)N;
+                bm[(size_t)n * v->ld_spec + k] = (float)((double)win[n] * ck * std::cos(ang) / N);
+                bm[(size_t)n * v->ld_spec + v->im_off + k] = (float)(-(double)win[n] * ck * std::sin(ang) / N);
+            }
+        W.basis = P.panel_from(bm.data(), nullptr, 0, N, v->ld_spec, 1);
+    }
+    if (!P.ok) { set_error(P.why); return -1; }
+    c->packed = true;
+    return 0;
+}
+
+struct VocosBufs { float *MEL, *X, *Y, *H, *SPEC, *FR; };
+static void vocos_plan(const mtts_vocos* v, int B, int T, WS& ws, VocosBufs& b) {
+    const size_t M = (size_t)B * T;
+    b.MEL = ws.f(M * round_up(v->n_mels, 4));
+    b.X = ws.f(M * v->dim); b.Y = ws.f(M * v->dim); b.H = ws.f(M * v->inter);
+    b.SPEC = ws.f(M * v->ld_spec); b.FR = ws.f(M * v->n_fft);
+}
+
+mtts_vocos* mtts_vocos_create(int n_mels, int dim, int inter, int layers, int n_fft, int hop) {
+    if (n_mels <= 0 || (n_mels & 3) || dim <= 0 || (dim & 3) || dim > 2048 || inter <= 0 || (inter & 3) || layers < 0 || n_fft <= 0 ||
+        (n_fft & 3) || hop <= 0 || n_fft % hop) {
+        set_error("mtts_vocos_create: unsupported shape (channels multiples of 4, dim <= 2048, hop divides n_fft)");
+        return nullptr;
+    }
+    mtts_vocos* v = new mtts_vocos();
+    v->n_mels = n_mels; v->dim = dim; v->inter = inter; v->layers = layers; v->n_fft = n_fft; v->hop = hop;
+    return v;
+}
+void mtts_vocos_destroy(mtts_vocos* v) {
+    if (!v) return;
+    for (hipEvent_t e : v->base.ev_pool) (void)hipEventDestroy(e);
+    delete v;
+}
+int mtts_vocos_set_tensor(mtts_vocos* v, const char* key, const float* h, int64_t numel) {
+    if (!v) { set_error("null context"); return -1; }
+    return mtts_set_tensor(&v->base, key, h, numel);
+}
+int64_t mtts_vocos_weights_bytes(mtts_vocos* v) {
+    if (!v) { set_error("null context"); return -1; }
+    if (!v->base.packed && vocos_pack(v)) return -1;
+    return (int64_t)(v->base.image.size() * sizeof(float));
+}
+int mtts_vocos_upload_weights(mtts_vocos* v, void* d_weights, int64_t bytes) {
+    if (!v || !d_weights) { set_error("mtts_vocos_upload_weights: bad argument"); return -1; }
+    if (!v->base.packed && vocos_pack(v)) return -1;
+    mtts_ctx* c = &v->base;
+    if ((size_t)bytes < c->image.size() * sizeof(float)) { set_error("weight buffer too small"); return -1; }
+    HIP_OK(hipMemcpy(d_weights, c->image.data(), c->image.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->d_image = static_cast<float*>(d_weights);
+    c->uploaded = true;
+    return 0;
+}
+int64_t mtts_vocos_workspace_bytes(mtts_vocos* v, int B, int T) {
+    if (!v) { set_error("null context"); return -1; }
+    WS ws(nullptr, 0);
+    VocosBufs b;
+    vocos_plan(v, B, T, ws, b);
+    return (int64_t)ws.off + 256;
+}
+
+// Vocos.decode (reference matcha/vocos24k/vocos_wrapper.py:8-9): mel [B, n_mels, T] -> audio [B, hop*(T-1)]
+int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_audio, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!v) { set_error("null context"); return -1; }
+    mtts_ctx* c = &v->base;
+    RET_IF(check_ready(c));
+    if (T < 2) { set_error("mtts_vocos_decode: need at least 2 frames"); return -1; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WS ws(d_ws, (size_t)ws_bytes);
+    VocosBufs b;
+    vocos_plan(v, B, T, ws, b);
+    if (ws.overflow) { set_error("vocos workspace too small"); return -1; }
+    const VocosW& Wt = v->w;
+    const int C = v->dim, M = B * T, ldm = round_up(v->n_mels, 4), nb = v->n_fft / 2 + 1;
+    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mel, nullptr, B, v->n_mels, T, b.MEL, ldm, 0, s));
+    {   // embed: Conv1d(n_mels -> dim, k7, pad 3), then LayerNorm(eps 1e-6)
+        GemmArgs a;
+        panel_args(c, Wt.embed, a); rows_plain(a, B, T); taps_centered(a, 7);
+        a.a0 = b.MEL; a.lda0 = ldm; a.c0 = v->n_mels; a.out = b.Y; a.ldc = C;
+        RET_IF(run_gemm(c, a, s));
+        LayerNormArgs ln;
+        ln.x = b.Y; ln.ldx = C; ln.y = b.X; ln.ldy = C; ln.M = M; ln.C = C; ln.T = T; ln.eps = 1e-6f;
+        ln.gamma = W(c, Wt.norm_g.off); ln.beta = W(c, Wt.norm_b.off);
+        LAUNCH(c, 2, 0, s, launch_layernorm(ln, s));
+    }
+    for (int i = 0; i < v->layers; ++i) {   // ConvNeXtBlock: x += gamma * pwconv2(GELU(pwconv1(LN(dwconv(x)))))
+        LAUNCH(c, 2, 0, s, launch_dwconv7_ln(b.X, W(c, Wt.dw_w[i].off), W(c, Wt.dw_b[i].off), W(c, Wt.ln_g[i].off), W(c, Wt.ln_b[i].off),
+                                             1e-6f, B, T, C, b.Y, s));
+        GemmArgs p1;
+        panel_args(c, Wt.pw1[i], p1); rows_plain(p1, B, T);
+        p1.a0 = b.Y; p1.lda0 = C; p1.c0 = C; p1.act = ACT_GELU; p1.out = b.H; p1.ldc = v->inter;
+        RET_IF(run_gemm(c, p1, s));
+        GemmArgs p2;
+        panel_args(c, Wt.pw2[i], p2); rows_plain(p2, B, T);
+        p2.a0 = b.H; p2.lda0 = v->inter; p2.c0 = v->inter; p2.res = b.X; p2.ldr = C; p2.out = b.X; p2.ldc = C;
+        RET_IF(run_gemm(c, p2, s));
+    }
+    {
+        LayerNormArgs ln;
+        ln.x = b.X; ln.ldx = C; ln.y = b.Y; ln.ldy = C; ln.M = M; ln.C = C; ln.T = T; ln.eps = 1e-6f;
+        ln.gamma = W(c, Wt.fin_g.off); ln.beta = W(c, Wt.fin_b.off);
+        LAUNCH(c, 2, 0, s, launch_layernorm(ln, s));
+        GemmArgs h;   // ISTFTHead.out
+        panel_args(c, Wt.head, h); rows_plain(h, B, T);
+        h.a0 = b.Y; h.lda0 = C; h.c0 = C; h.out = b.SPEC; h.ldc = v->ld_spec;
+        RET_IF(run_gemm(c, h, s));
+        LAUNCH(c, 2, 0, s, launch_spec_polar(b.SPEC, M, v->ld_spec, nb, v->im_off, 1e2f, s));
+        GemmArgs d;   // irfft * window as a GEMM
+        panel_args(c, Wt.basis, d); rows_plain(d, B, T);
+        d.a0 = b.SPEC; d.lda0 = v->ld_spec; d.c0 = v->ld_spec; d.out = b.FR; d.ldc = v->n_fft;
+        RET_IF(run_gemm(c, d, s));
+        LAUNCH(c, 2, 0, s, launch_istft_ola(b.FR, W(c, Wt.window.off), B, T, v->n_fft, v->hop, d_audio, s));
+    }
     return 0;
 }
 

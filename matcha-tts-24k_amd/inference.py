@@ -181,17 +181,16 @@ def process_text(text: str, language: str):
     return {"x_orig": text, "x": x, "x_lengths": x_lengths, "x_phones": "".join(separated), "x_phone_ids": ids}
 
 
-def load_vocoder(vocoder_name):
-    """reference inference.py:223-231.  The Vocos head is SURVEY section 8f item 1 (next); until it is built the
-    reference's own vocoder object is used when its package is installed."""
+def load_vocoder(vocoder_name, checkpoint=None, state_dict=None):
+    """reference inference.py:223-231.  The Vocos-24k head runs on the HIP library (vocoder.py); weights come from a local
+    file (``VOCOS_CHECKPOINT``) because the reference's ``from_pretrained`` hub fetch needs a network."""
+    print(f"[!] Loading {vocoder_name}!")
     if vocoder_name != "vocos":
         raise NotImplementedError(f"Vocoder {vocoder_name} not implemented!")
-    try:
-        from matcha.vocos24k.vocos_wrapper import load_model  # type: ignore
-    except Exception as e:  # pragma: no cover
-        raise NotImplementedError("the Vocos-24k head is not part of this package yet (SURVEY 8f-1) and the "
-                                  "reference's vocos wrapper is not installed") from e
-    return load_model(DEVICE)
+    from .vocoder import load_model
+    vocoder = load_model(DEVICE, checkpoint=checkpoint, state_dict=state_dict)
+    print(f"[+] {vocoder_name} loaded!")
+    return vocoder
 
 
 def to_waveform(mel, vocoder):

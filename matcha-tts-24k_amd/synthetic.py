@@ -241,3 +241,48 @@ def cpu_noise(shape, seed: int = 42) -> torch.Tensor:
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Vocos-24k head (shapes from reference matcha/vocos24k/config.yaml:10-24; key names of the vocos package)
+# --------------------------------------------------------------------------------------
+def vocos_spec(n_mels: int = 100, dim: int = 512, inter: int = 1536, layers: int = 8, n_fft: int = 1024):
+    out = [("backbone.embed.weight", (dim, n_mels, 7), "w"), ("backbone.embed.bias", (dim,), "b"),
+           ("backbone.norm.weight", (dim,), "g"), ("backbone.norm.bias", (dim,), "nb")]
+    for i in range(layers):
+        p = f"backbone.convnext.{i}."
+        out += [(p + "dwconv.weight", (dim, 1, 7), "w"), (p + "dwconv.bias", (dim,), "b"),
+                (p + "norm.weight", (dim,), "g"), (p + "norm.bias", (dim,), "nb"),
+                (p + "pwconv1.weight", (inter, dim), "w"), (p + "pwconv1.bias", (inter,), "b"),
+                (p + "pwconv2.weight", (dim, inter), "w"), (p + "pwconv2.bias", (dim,), "b"),
+                (p + "gamma", (dim,), "ls")]
+    out += [("backbone.final_layer_norm.weight", (dim,), "g"), ("backbone.final_layer_norm.bias", (dim,), "nb"),
+            ("head.out.weight", (n_fft + 2, dim), "head_w"), ("head.out.bias", (n_fft + 2,), "head_b")]
+    return out
+
+
+def make_vocos_state_dict(seed: int = 11, **kw) -> Dict[str, torch.Tensor]:
+    """Random-init Vocos weights (the pretrained charactr/vocos-mel-24khz cannot be fetched offline)."""
+    layers = kw.get("layers", 8)
+    sd: Dict[str, torch.Tensor] = {}
+    for key, shape, kind in vocos_spec(**kw):
+        n = int(np.prod(shape))
+        z = portable_normal(seed, _stream_of("vocos." + key), n)
+        if kind == "w":
+            v = z / math.sqrt(int(np.prod(shape[1:])))
+        elif kind == "b":
+            v = 0.05 * z
+        elif kind == "g":
+            v = 1.0 + 0.1 * z
+        elif kind == "nb":
+            v = 0.1 * z
+        elif kind == "ls":                      # layer scale, init 1/num_layers
+            v = (1.0 / layers) * (1.0 + 0.2 * z)
+        elif kind == "head_w":                  # keep log-magnitudes moderate so exp() stays inside the 1e2 clip mostly
+            v = 0.5 * z / math.sqrt(shape[1])
+        elif kind == "head_b":
+            v = 0.1 * z
+        else:
+            raise KeyError(kind)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32).reshape(shape).copy())
+    return sd
