@@ -80,8 +80,8 @@ def load() -> C.CDLL:
         "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
         "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
-        "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp,
-                                i32, vp, f32, vp, i32, vp]),
+        "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
+                                i32, vp, f32, vp, i32, vp, vp]),
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
@@ -310,7 +310,7 @@ class HipModel:
 
 # ---------------------------------------------------------------------- single kernels (used by the parity tests)
 def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1, a_mask=None, a_mean=None, a_rstd=None,
-             act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0):
+             a_part=None, act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0, stats_out=False):
     """a [B*T_in, C]; w Linear [N, C] or Conv1d [N, C, k]."""
     lib = load()
     N, Cc = w.shape[0], w.shape[1]
@@ -319,10 +319,13 @@ def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1,
     taps = (C.c_int * ntaps)(*(tap_off if tap_off is not None else [j - ntaps // 2 for j in range(ntaps)]))
     packed = torch.empty(lib.mtts_gemm_packed_bytes(N, Cc, ntaps), dtype=torch.uint8, device=a.device)
     out = torch.empty(B * T_out, N, dtype=torch.float32, device=a.device)
+    stats = torch.empty(B * T_out, N // 64, 2, dtype=torch.float32, device=a.device) if stats_out else None
     check(lib.mtts_gemm_f32(ptr(a), a.shape[1], B, T_in, Cc, ntaps, taps, in_stride, T_out, ptr(a_mask), ptr(a_mean), ptr(a_rstd),
+                            ptr(a_part), a_part.shape[1] if a_part is not None else 0,
                             ptr(w.contiguous()), packed.data_ptr(), ptr(bias), N, act, ptr(p0), ptr(p1), ptr(res),
-                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, stream_ptr()))
-    return out
+                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, ptr(stats),
+                            stream_ptr()))
+    return (out, stats) if stats_out else out
 
 
 def attention_f32(qkv, mask, B, T, H, D, scale, mask_mode):

@@ -46,6 +46,23 @@ __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1)
 
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2), used when the 128-row grid would leave
 // CUs with a single resident workgroup (nothing to overlap its staging with).
+// DPP all-reduce sums (every lane gets the total): 16-lane rows via row_mirror, row_half_mirror, quad reverse, quad swap;
+// 8-lane groups skip the first step.  One VALU instruction per step instead of a ds_bpermute round trip.
+#define MTTS_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ float allreduce16(float v) {
+    v = MTTS_DPP_ADD(v, 0x140);   // row_mirror
+    v = MTTS_DPP_ADD(v, 0x141);   // row_half_mirror
+    v = MTTS_DPP_ADD(v, 0x1B);    // quad_perm [3,2,1,0]
+    v = MTTS_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
+    return v;
+}
+__device__ __forceinline__ float allreduce8(float v) {
+    v = MTTS_DPP_ADD(v, 0x141);
+    v = MTTS_DPP_ADD(v, 0x1B);
+    v = MTTS_DPP_ADD(v, 0xB1);
+    return v;
+}
+
 template <int BM, bool A_MASK, bool A_NORM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along M
@@ -110,7 +127,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             const int row = ok ? arow_base[i] + tin : 0;
             ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)row * ld + (ok ? cc : 0));
             r_ok[i] = ok;
-            if (A_NORM) { r_mean[i] = p.a_mean[row]; r_rstd[i] = p.a_rstd[row]; }
             if (A_MASK) { r_mask[i] = p.a_mask[row]; }
         }
         const float* wp = wrow + ld_tap * p.ktap + ld_c;
@@ -143,7 +159,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = Kp / GEMM_BK;
+    // LayerNorm prologue (ntaps == 1: a thread's rows are the same for every k-step).  Statistics come either from arrays
+    // or from the 64-column partial moments the producing GEMM left behind: the 8 threads tid&7 that stage one row each load
+    // one partial (issued BEFORE the first tile fetch so they return first) and merge them with an equal-count Chan merge.
+    const int pj = tid & 7;
+    float2 pstat[AR];
+    int prow[AR];
+    if (A_NORM) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int tin = at[i];
+            prow[i] = (unsigned)tin < (unsigned)p.T_in ? arow_base[i] + tin : 0;
+            if (p.a_part) {
+                const float* q = p.a_part + (size_t)prow[i] * p.a_nparts * 2;
+                float2 acc2 = {0.f, 0.f};
+                for (int k = pj; k < p.a_nparts; k += 8) {
+                    const float2 v = *reinterpret_cast<const float2*>(q + 2 * k);
+                    acc2.x += v.x;
+                    acc2.y += v.y;
+                }
+                pstat[i] = acc2;
+            } else {
+                pstat[i] = float2{p.a_mean[prow[i]], p.a_rstd[prow[i]]};
+            }
+        }
+    }
     fetch();
+    if (A_NORM) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            if (p.a_part) {
+                float m2 = pstat[i].y;
+                const float mean = allreduce8(pstat[i].x) / (float)p.a_nparts;
+                if (p.a_nparts <= 8) {
+                    if (pj < p.a_nparts) { const float d = pstat[i].x - mean; m2 += 64.0f * (d * d); }
+                } else {
+                    const float* q = p.a_part + (size_t)prow[i] * p.a_nparts * 2;
+                    for (int k = pj; k < p.a_nparts; k += 8) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                }
+                r_mean[i] = mean;
+                r_rstd[i] = 1.0f / sqrtf(allreduce8(m2) / (64.0f * (float)p.a_nparts) + p.a_eps);
+            } else {
+                r_mean[i] = pstat[i].x;
+                r_rstd[i] = pstat[i].y;
+            }
+        }
+    }
+
     stage(0);
     __syncthreads();
 
@@ -222,6 +284,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             f32x4 o = {c[0], c[1], c[2], c[3]};
             if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)orow * p.ldr + nc);
             *reinterpret_cast<f32x4*>(op) = o;
+            if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 16 lanes lane&15 hold them
+                const float mean = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
+                const f32x4 d = o - mean;
+                const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                if ((lane & 15) == 0) {
+                    float* so = p.stats_out + ((size_t)orow * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                    so[0] = mean;
+                    so[1] = m2;
+                }
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -248,7 +320,7 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
 
 template <int BM>
 static hipError_t launch_bm(const GemmArgs& a, hipStream_t s) {
-    const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr;
+    const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr || a.a_part != nullptr;
     if (mk && nm) return launch_variant<BM, true, true>(a, s);
     if (mk) return launch_variant<BM, true, false>(a, s);
     if (nm) return launch_variant<BM, false, true>(a, s);
@@ -265,6 +337,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (!a.a1 && a.c1) return hipErrorInvalidValue;
     if (a.lda0 < a.c0 || (a.a1 && a.lda1 < a.c1)) return hipErrorInvalidValue;
     if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
+    if (a.a_part && (a.a_mean || a.a_nparts <= 0)) return hipErrorInvalidValue;
+    if ((a.a_mean || a.a_part) && (a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0)) return hipErrorInvalidValue;
+    if (a.stats_out && ((a.N & 63) || (a.ldc & 3) || (a.res && (a.ldr & 3)))) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
     // Block-tile height: 256 CUs x 2 resident workgroups = 512 slots per round; pick the height whose grid wastes the
     // least of its last round (e.g. M=10240, N=1152: 720 tiles of 128 rows fill 70 % of two rounds, 1440 tiles of 64

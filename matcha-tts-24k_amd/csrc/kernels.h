@@ -28,8 +28,11 @@ struct GemmArgs {
     int in_stride = 1;           // t_in = t_out * in_stride + tap_off[tap]
     int B = 1, T_in = 1, T_out = 1;   // M = B * T_out
     const float* a_mask = nullptr;    // [B*T_in]  multiply A rows
-    const float* a_mean = nullptr;    // [B*T_in]  (x - mean) * rstd   (LayerNorm with the affine folded into W)
+    const float* a_mean = nullptr;    // [B*T_in]  (x - mean) * rstd   (LayerNorm with the affine folded into W); ntaps == 1
     const float* a_rstd = nullptr;
+    const float* a_part = nullptr;    // alternative to a_mean/a_rstd: per-row partial moments [B*T_in][a_nparts][2] = (mean, M2) of
+    int a_nparts = 0;                 //   64-column slices, written by the producing GEMM's epilogue (stats_out); merged in the prologue
+    float a_eps = 1e-5f;
     // ---- B operand: packed [Np][Kp], Np = round_up(N,128), Kp = ntaps * ktap
     const float* w = nullptr;
     const float* bias = nullptr;      // [Np] or null
@@ -44,6 +47,7 @@ struct GemmArgs {
     int ldr = 0;
     float* out = nullptr;
     int ldc = 0;
+    float* stats_out = nullptr;       // [M][N/64][2]: (mean, M2) of every 64-column slice of the output rows (N % 64 == 0)
     int out_T = 1, out_stride = 1, out_off = 0;   // output row = b*out_T + t*out_stride + out_off
     int force_bm = 0;                 // 0 = choose the block tile height from the grid size; 64 / 128 = force (tests)
 };

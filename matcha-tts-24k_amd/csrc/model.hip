@@ -344,7 +344,7 @@ struct DecBufs {
     std::vector<float*> mask;            // [B*T_l]
     std::vector<float*> bufA, bufB, skip;
     float *Y = nullptr, *Hh = nullptr, *Rr = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
-    float *mean = nullptr, *rstd = nullptr, *gnp = nullptr;
+    float *mean = nullptr, *rstd = nullptr, *gnp = nullptr, *lnp = nullptr;
     float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
     float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
     int ldx = 0, ldv = 0;
@@ -371,6 +371,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     d.Y = ws.f(M0 * cmax); d.Hh = ws.f(M0 * cmax); d.Rr = ws.f(M0 * cmax);
     d.QKV = ws.f(M0 * 3 * inner); d.ATT = ws.f(M0 * inner); d.FF = ws.f(M0 * 4 * cmax);
     d.mean = ws.f(M0); d.rstd = ws.f(M0);
+    d.lnp = ws.f(M0 * (size_t)((cmax + 63) / 64) * 2);
     d.gnp = ws.f((size_t)B * gn_chunks(T) * 8 * 2);
     d.ldx = round_up(2 * g.n_feats, GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
@@ -440,13 +441,22 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
 }
 
 // BasicTransformerBlock.forward (reference transformer.py:230-303, self-attention only), in place on x [B*T, C].
-static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x, int C, int lvl, hipStream_t s) {
+// LayerNorm statistics travel with the data: the GEMM that writes x (attention out-projection, second FF projection)
+// leaves per-row partial moments of its 64-column slices behind (stats_out) and the next projection merges them in its
+// prologue, so only the first LayerNorm after a ResNet block needs the row_stats kernel.
+static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x, int C, int lvl, bool have_stats, bool emit_stats,
+                             hipStream_t s) {
     const mtts_config& g = c->cfg;
     const int B = d.B, T = d.Tl[lvl], M = B * T, inner = g.dec_heads * g.dec_head_dim;
-    LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
+    const bool fuse = (C % 64) == 0;
     GemmArgs q;
     panel_args(c, t.qkv, q); rows_plain(q, B, T);
-    q.a0 = x; q.lda0 = C; q.c0 = C; q.a_mean = d.mean; q.a_rstd = d.rstd; q.out = d.QKV; q.ldc = 3 * inner;
+    q.a0 = x; q.lda0 = C; q.c0 = C; q.out = d.QKV; q.ldc = 3 * inner;
+    if (fuse && have_stats) { q.a_part = d.lnp; q.a_nparts = C / 64; }
+    else {
+        LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
+        q.a_mean = d.mean; q.a_rstd = d.rstd;
+    }
     RET_IF(run_gemm(c, q, s));
     AttnArgs at;
     at.qkv = d.QKV; at.mask = d.mask[lvl]; at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
@@ -455,16 +465,22 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
     GemmArgs o;
     panel_args(c, t.out, o); rows_plain(o, B, T);
     o.a0 = d.ATT; o.lda0 = inner; o.c0 = inner; o.res = x; o.ldr = C; o.out = x; o.ldc = C;
+    if (fuse) o.stats_out = d.lnp;
     RET_IF(run_gemm(c, o, s));
-    LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
     GemmArgs f1;
     panel_args(c, t.ff1, f1); rows_plain(f1, B, T);
-    f1.a0 = x; f1.lda0 = C; f1.c0 = C; f1.a_mean = d.mean; f1.a_rstd = d.rstd; f1.act = ACT_SNAKE;
+    f1.a0 = x; f1.lda0 = C; f1.c0 = C; f1.act = ACT_SNAKE;
     f1.p0 = W(c, t.alpha_exp.off); f1.p1 = W(c, t.inv_beta.off); f1.out = d.FF; f1.ldc = 4 * C;
+    if (fuse) { f1.a_part = d.lnp; f1.a_nparts = C / 64; }
+    else {
+        LAUNCH(c, 2, 0, s, launch_row_stats(x, M, C, C, 1e-5f, d.mean, d.rstd, s));
+        f1.a_mean = d.mean; f1.a_rstd = d.rstd;
+    }
     RET_IF(run_gemm(c, f1, s));
     GemmArgs f2;
     panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
     f2.a0 = d.FF; f2.lda0 = 4 * C; f2.c0 = 4 * C; f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C;
+    if (fuse && emit_stats) f2.stats_out = d.lnp;
     RET_IF(run_gemm(c, f2, s));
     return 0;
 }
@@ -487,7 +503,7 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     for (int l = 0; l < nl; ++l) {
         const ResnetW& r = D.res[ri++];
         RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, nullptr, 0, 0, l, tb + r.tb_off, d.skip[l], s));
-        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], d.skip[l], r.cout, l, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], d.skip[l], r.cout, l, j > 0, j + 1 < nb, s));
         GemmArgs a;
         panel_args(c, D.down[l], a);
         taps_centered(a, 3);
@@ -510,7 +526,7 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
         const ResnetW& r = D.res[ri++];
         float* dst = (cur == d.bufA[lm]) ? d.bufB[lm] : d.bufA[lm];
         RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, nullptr, 0, 0, lm, tb + r.tb_off, dst, s));
-        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, lm, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, lm, j > 0, j + 1 < nb, s));
         cur = dst; cur_ld = r.cout; cur_c = r.cout;
     }
     // ---- up path
@@ -520,7 +536,7 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
         const int cskip = g.dec_channels[l];
         float* dst = (cur == d.bufA[l]) ? d.bufB[l] : d.bufA[l];
         RET_IF(resnet_block(c, d, r, cur, cur_ld, cur_c, d.skip[l], cskip, cskip, l, tb + r.tb_off, dst, s));
-        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, l, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], dst, r.cout, l, j > 0, j + 1 < nb, s));
         if (i < nl - 1) {   // Upsample1D: ConvTranspose1d(k4, s2, p1) as two phase GEMMs (reference decoder.py:146)
             float* up = d.bufA[l - 1];
             for (int ph = 0; ph < 2; ++ph) {
@@ -888,9 +904,10 @@ int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps) {
 }
 
 int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride, int T_out,
-                  const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_w, void* d_wpacked,
-                  const float* d_bias, int N, int act, const float* d_p0, const float* d_p1, const float* d_res, int ldr,
-                  const float* d_out_mask, float out_scale, float* d_out, int ldc, void* stream) {
+                  const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_a_part, int a_nparts,
+                  const float* d_w, void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
+                  const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc, float* d_stats_out,
+                  void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
     if (d_w) HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));   // NULL: d_wpacked already packed
@@ -898,7 +915,8 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
     a.a0 = d_a; a.lda0 = lda; a.c0 = C; a.ktap = round_up(C, GEMM_BK); a.ntaps = ntaps;
     for (int j = 0; j < ntaps; ++j) a.tap_off[j] = h_tap_off ? h_tap_off[j] : 0;
     a.in_stride = in_stride; a.B = B; a.T_in = T_in; a.T_out = T_out;
-    a.a_mask = d_a_mask; a.a_mean = d_a_mean; a.a_rstd = d_a_rstd;
+    a.a_mask = d_a_mask; a.a_mean = d_a_mean; a.a_rstd = d_a_rstd; a.a_part = d_a_part; a.a_nparts = a_nparts;
+    a.stats_out = d_stats_out;
     a.w = static_cast<const float*>(d_wpacked); a.bias = d_bias; a.N = N; a.act = act; a.p0 = d_p0; a.p1 = d_p1;
     a.res = d_res; a.ldr = ldr; a.out_mask = d_out_mask; a.out_scale = out_scale; a.out = d_out; a.ldc = ldc;
     a.out_T = T_out; a.out_stride = 1; a.out_off = 0;

@@ -112,6 +112,27 @@ def test_layernorm_prologue_and_snake(hip):
     close(out, ref, 1e-5)
 
 
+def test_layernorm_stats_travel_through_epilogue(hip):
+    """GEMM 1 writes x = a.W1^T + res and leaves (mean, M2) partials of its 64-column slices; GEMM 2 merges them in its
+    prologue as the LayerNorm of x.  Must equal the two-pass statistics of row_stats on x."""
+    for B, T in ((2, 100), (8, 1000)):      # 64-row and 128-row block tiles
+        C = 384
+        a, r = rnd(B * T, C, seed=51), rnd(B * T, C, seed=52) * 2 + 0.5
+        w1, b1 = rnd(C, C, seed=53, scale=C ** -0.5), rnd(C, seed=54)
+        w2, b2 = rnd(1152, C, seed=55, scale=C ** -0.5), rnd(1152, seed=56)
+        x, stats = hip.gemm_f32(a.cuda(), w1.cuda(), b1.cuda(), B=B, T_in=T, res=r.cuda(), stats_out=True)
+        xd = x.cpu().double()
+        assert torch.allclose(stats[:, :, 0].cpu().double(), xd.view(B * T, 6, 64).mean(-1), atol=1e-5)
+        mean, rstd = hip.row_stats(x)
+        y_ref = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd)
+        y = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_part=stats)
+        mu = xd.mean(1, keepdim=True)
+        var = ((xd - mu) ** 2).mean(1, keepdim=True)
+        ref = F.linear((xd - mu) / torch.sqrt(var + 1e-5), w2.double(), b2.double())
+        close(y, ref, 1e-5)
+        assert (y - y_ref).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0),
                                            (8, 1024, 12, 64, 0), (8, 1000, 12, 48, 1)])   # the last two run the 128-query block variant
 def test_attention(hip, oracle, B, T, H, D, mode):

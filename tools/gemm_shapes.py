@@ -39,10 +39,16 @@ SHAPES = [  # name, B, T_in, T_out, C, ntaps, stride, N, mask, norm, act, res, c
 ]
 
 
+FUSED = False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--fused-stats", action="store_true", help="LayerNorm stats via epilogue partials (as the decoder runs them)")
     args = ap.parse_args()
+    global FUSED
+    FUSED = args.fused_stats
     lib = hip.load()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
@@ -58,14 +64,19 @@ def main():
         p1 = torch.ones(N, device=dev) if act == 3 else None
         r = torch.randn(B * To, N, device=dev) if res else None
         out = torch.empty(B * To, N, device=dev)
+        part_in = bool(nm) and FUSED and Cc % 64 == 0
+        st_out = bool(res) and FUSED and N % 64 == 0
+        part = torch.zeros(B * Ti, max(Cc // 64, 1), 2, device=dev)
+        part[:, :, 1] = 64.0
+        stats = torch.empty(B * To, max(N // 64, 1), 2, device=dev)
         packed = torch.empty(lib.mtts_gemm_packed_bytes(N, Cc, nt), dtype=torch.uint8, device=dev)
         taps = (C.c_int * nt)(*[j - nt // 2 for j in range(nt)])
         s = hip.stream_ptr()
 
         def launch(wptr):
-            hip.check(lib.mtts_gemm_f32(hip.ptr(a), Cc, B, Ti, Cc, nt, taps, st, To, hip.ptr(mask), hip.ptr(mean), hip.ptr(rstd), wptr,
+            hip.check(lib.mtts_gemm_f32(hip.ptr(a), Cc, B, Ti, Cc, nt, taps, st, To, hip.ptr(mask), hip.ptr(mean) if not part_in else None, hip.ptr(rstd) if not part_in else None, hip.ptr(part) if part_in else None, part.shape[1] if part_in else 0, wptr,
                                         packed.data_ptr(), hip.ptr(bias), N, act, hip.ptr(p0), hip.ptr(p1), hip.ptr(r), N if res else 0,
-                                        None, 1.0, hip.ptr(out), N, s))
+                                        None, 1.0, hip.ptr(out), N, hip.ptr(stats) if st_out else None, s))
         launch(hip.ptr(w.contiguous()))
         for _ in range(3):
             launch(None)
