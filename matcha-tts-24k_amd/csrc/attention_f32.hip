@@ -24,6 +24,10 @@ constexpr int AT_K = 64;      // keys per tile
 constexpr int AT_D = 64;      // padded head dim
 constexpr int AT_S = 68;      // LDS row stride (floats): 17 x 16 B, conflict-free b128 row reads
 constexpr float NEG_BIG = -1e30f;
+constexpr float LOG2E = 1.44269504088896340736f;
+// exp(x) for x <= 0 as one v_exp_f32 (2^t, ~1 ulp) after an exact-to-rounding scale by log2(e): the softmax weights
+// carry ~1e-6 relative error at |x| ~ 10, far inside the path's 1e-3 budget, and cost 3 VALU ops instead of ~20.
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
 
 // NW waves per workgroup = NW*32 queries.  NW = 4 for long sequences; NW = 2 when T is short enough that 128-query
 // blocks would leave the last block mostly empty or the grid under one round (e.g. T = 320: 3 blocks of 128 waste 17 %).
@@ -159,13 +163,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = exp_neg(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = expf(s[t][r] - m_new);
+                const float pv = exp_neg(s[t][r] - m_new);
                 s[t][r] = pv;
                 psum += pv;
             }

@@ -121,6 +121,37 @@ def test_tiny_batched_ragged_vs_oracle(tiny, synthetic, oracle, dev):
     assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
 
 
+# ------------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("lengths", [[1], [2, 1], [3, 12, 1]])
+def test_tiny_minimal_lengths_vs_oracle(tiny, synthetic, oracle, dev, lengths):
+    """One-token utterances: T_pad = 6 (3 frames at the coarse level), ragged against a full-length neighbour."""
+    hp, sd, model = tiny
+    B, Tx = len(lengths), max(lengths)
+    x, x_len, spk = synthetic.make_inputs(hp, B, Tx, seed=5, lengths=lengths)
+    model.decoder.solver = "euler"
+    with torch.inference_mode():
+        ref = oracle.synthesise(sd, hp, x, x_len, 2, speaker=spk, solver="euler")
+    z = synthetic.cpu_noise((B, hp.n_feats, ref["t_pad"])).to(dev)
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=spk.to(dev), debug=True, z=z)
+    assert out["mel"].shape == ref["mel"].shape
+    assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"])
+    assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
+
+
+def test_long_utterance_runs_and_matches_oracle_prefix_properties(prod, synthetic, dev):
+    """Tx = 1500 tokens -> T_pad = 7500 decoder frames (the server's input cap gives <= ~3000 tokens): finite, deterministic,
+    right shape.  (An oracle run at this length takes minutes of CPU; parity at length is covered by the 640-frame goldens.)"""
+    hp, sd, model = prod
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 1500, seed=9)
+    model.decoder.solver = "euler"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0)["mel"]
+    assert out.shape == (1, 100, 3750) and torch.isfinite(out).all()
+    assert torch.equal(out, model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0)["mel"])
+    with pytest.raises(AssertionError):
+        model.encoder(torch.zeros(1, 4001, dtype=torch.long, device=dev), torch.tensor([4001], device=dev),
+                      torch.zeros(1, 96, device=dev), torch.zeros(1, 96, device=dev))   # reference RoPE cache limit
+
+
 # ------------------------------------------------------------------------------------------------ glue kernels
 def test_durations_and_alignment_vs_oracle(oracle, dev):
     """Ragged integer durations incl. zeros beyond x_len, odd total lengths, scale factors: bit-exact integer work,
