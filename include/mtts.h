@@ -128,6 +128,9 @@ int mtts_cfm_solve(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const fl
  * (d_w = NULL: d_wpacked already holds the packed panel from an earlier call).
  * act: 0 none, 1 relu, 2 silu, 3 SnakeBeta with d_p0 = exp(alpha)[N], d_p1 = 1/(exp(beta)+1e-9)[N]
  * (reference transformer.py:61-77).  Epilogue: c = act(acc + bias); c *= out_mask[row]; c = c*out_scale + res[row][n].
+ * terms: arithmetic of the products: 0 = v_mfma_f32_32x32x2_f32 (native fp32), 6 = fp32-equivalent on the bf16 matrix
+ * cores (operands split into three exact bf16 terms, six products, fp32 accumulate), 3 = two-term split (opt-in),
+ * -1 = the library default (6, or MTTS_GEMM_TERMS).
  * LayerNorm prologue: either d_a_mean/d_a_rstd [rows], or d_a_part [rows][a_nparts][2] = (mean, M2) of 64-column slices
  * as written by a previous call's d_stats_out [M][N/64][2] (N % 64 == 0).  All optional pointers may be NULL. */
 int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps);
@@ -136,7 +139,7 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
                   int a_nparts, const float* d_w,
                   void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
                   const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc,
-                  float* d_stats_out, void* stream);
+                  float* d_stats_out, int terms, void* stream);
 
 /* Self-attention over packed [B*T, 3*H*D] q|k|v rows -> [B*T, H*D].  mask_mode 0: additive float key bias
  * (diffusers semantics, reference transformer.py:253-258); 1: boolean query*key mask (reference

@@ -39,8 +39,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         newest = max(p.stat().st_mtime for p in srcs + HEADERS)
         if LIB.stat().st_mtime >= newest:
             return LIB
+    # -ffp-contract=off: keep the reference's rounding points (no silent FMA fusion in the element-wise math).
+    # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent fp32 ops into v_pk_mul_f32 / v_pk_add_f32; in the
+    #   split-bf16 GEMM staging (LayerNorm prologue -> bf16 split -> LDS store) that produced sporadically wrong values in
+    #   lanes 48-63 of a wave on gfx950 (a missing wait state after the packed op; reproduced with tools/_dbg_stats.py,
+    #   gone with scalar fp32 ops).  Packed fp32 VALU is also slower beside MFMAs (cdna_hip_programming.md).
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
            *[str(s) for s in srcs], "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
@@ -81,7 +86,7 @@ def load() -> C.CDLL:
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
         "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
         "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
-                                i32, vp, f32, vp, i32, vp, vp]),
+                                i32, vp, f32, vp, i32, vp, i32, vp]),
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
@@ -310,7 +315,7 @@ class HipModel:
 
 # ---------------------------------------------------------------------- single kernels (used by the parity tests)
 def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1, a_mask=None, a_mean=None, a_rstd=None,
-             a_part=None, act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0, stats_out=False):
+             a_part=None, act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0, stats_out=False, terms=-1):
     """a [B*T_in, C]; w Linear [N, C] or Conv1d [N, C, k]."""
     lib = load()
     N, Cc = w.shape[0], w.shape[1]
@@ -323,7 +328,7 @@ def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1,
     check(lib.mtts_gemm_f32(ptr(a), a.shape[1], B, T_in, Cc, ntaps, taps, in_stride, T_out, ptr(a_mask), ptr(a_mean), ptr(a_rstd),
                             ptr(a_part), a_part.shape[1] if a_part is not None else 0,
                             ptr(w.contiguous()), packed.data_ptr(), ptr(bias), N, act, ptr(p0), ptr(p1), ptr(res),
-                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, ptr(stats),
+                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, ptr(stats), terms,
                             stream_ptr()))
     return (out, stats) if stats_out else out
 

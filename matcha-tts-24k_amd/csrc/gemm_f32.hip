@@ -16,20 +16,47 @@
 //   LDS rows are K-contiguous, stride 36 floats: the 16-byte fragment reads (ds_read_b128) and tile writes are conflict free
 //   inside a group of 8 k the MFMA kk consumes k = {kk, 4+kk}: lane half h owns k = 4h..4h+3, i.e. one ds_read_b128
 //   feeds four MFMAs per operand (the k permutation is the same for A and W, so the sum is unchanged)
-// fp32-input MFMA is an exact fp32 FMA chain (157 TFLOP/s peak): results differ from a CPU GEMM only by summation order.
+// Arithmetic, template parameter TERMS:
+//   0  v_mfma_f32_32x32x2_f32: fp32 inputs, an exact fp32 FMA chain (157 TFLOP/s dense peak).
+//   6  fp32-equivalent on the bf16 matrix cores: every operand is the exact sum of three bf16 terms (8+8+8 significand
+//      bits, A split while staging, W pre-split in the weight image) and the six cross products whose weight is above
+//      2^-24 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (products of bf16 values are exact in fp32).  The
+//      dropped products are below fp32 rounding, so the result differs from the fp32 chain by summation order only
+//      (measured: same error vs fp64), at 6/16 of the fp32-MFMA cycles.
+//   3  two-term split, three products (weights above 2^-16): ~2^-17 relative per product; opt-in.
 #include "kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace mtts {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
 constexpr int LDS_STRIDE = GEMM_BK + 4;                              // 36 floats = 144 B (9 x 16 B)
 // one (A,B) stage of a BM x 128 block tile; two stages: BM=128 -> 73,728 B, BM=64 -> 55,296 B (2 workgroups per CU)
 constexpr int tile_floats(int BM) { return (BM + GEMM_BN) * LDS_STRIDE; }
-constexpr int gemm_lds_bytes(int BM) { return 2 * tile_floats(BM) * 4; }
+// Split mode (TERMS = 3 or 6, see below): one stage of NPL bf16 planes per operand, rows of 32 bf16 + 16 B pad = 80 B
+// (5 x 16-byte slots: the 16-byte fragment reads of 32 rows hit 16 different slots), single-buffered; the epilogue tile
+// (4 waves x BM/2 rows x 68 floats) reuses the same LDS and is the larger of the two at BM = 128.
+constexpr int SPLIT_RS = 40;                                         // row stride in bf16 elements
+constexpr int split_planes(int terms) { return terms == 6 ? 3 : 2; }
+constexpr int epi_bytes(int BM) { return 4 * (BM / 2) * 68 * 4; }
+constexpr int gemm_lds_bytes(int BM, int terms) {
+    const int stage = terms == 0 ? 2 * tile_floats(BM) * 4 : split_planes(terms) * (BM + GEMM_BN) * SPLIT_RS * 2;
+    return stage > epi_bytes(BM) ? stage : epi_bytes(BM);
+}
+
+// x = h + m + l exactly (three round-to-nearest bf16 terms of 8 significand bits each; the subtractions are exact)
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
 
 // sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 and the two minimax kernels on
 // [-pi/4, pi/4]; the quadrant only selects which kernel is squared, so no sign handling.  ~1 ulp of sinf for |y| < 1e4
@@ -80,11 +107,15 @@ __device__ __forceinline__ float allreduce8(float v) {
     return v;
 }
 
-template <int BM, bool A_MASK, bool A_NORM>
+__device__ __forceinline__ int round_up_dev(int n) { return (n + GEMM_BN - 1) / GEMM_BN * GEMM_BN; }
+
+template <int BM, bool A_MASK, bool A_NORM, int TERMS>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along M
     constexpr int AR = BM / 32;                 // A rows staged per thread
     constexpr int TILE_FLOATS = tile_floats(BM);
+    constexpr int NPL = split_planes(TERMS);    // bf16 planes per operand (split mode)
+    constexpr int APLANE = BM * SPLIT_RS, BPLANE = GEMM_BN * SPLIT_RS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,11 +153,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         }
     }
     const float* wrow = p.w + (size_t)(n0 + lrow) * Kp + lq;
+    // split mode: W planes [NPL of 3][Np][Kp] bf16; a thread stages rows (tid>>2) + 64 j, 8 bf16 (16 B) at k = (tid&3)*8
+    const int wr16 = tid >> 2, wc16 = (tid & 3) * 8;
+    const size_t wplane = (size_t)round_up_dev(p.N) * Kp;
+    const __bf16* wrow16 = reinterpret_cast<const __bf16*>(p.w16) + (size_t)(n0 + wr16) * Kp + wc16;
 
     // Tile fetch: every load is issued unconditionally (out-of-range rows read row 0 and are zeroed later), no load
     // depends on another load's result, and the mask / LayerNorm transform is deferred to the LDS write -- so the 8-20
     // loads of tile k+1 are all in flight under the MFMAs of tile k.
-    f32x4 ra[AR], rb[4];
+    f32x4 ra[AR], rb[TERMS == 0 ? 4 : 1];
+    bf16x8 rw[TERMS == 0 ? 1 : NPL][2];
     float r_mask[AR], r_mean[AR], r_rstd[AR];
     bool r_ok[AR];
     int ld_tap = 0, ld_c = 0;   // (tap, channel) of the next tile to fetch; a 32-wide K chunk never straddles segments
@@ -146,25 +182,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
             r_ok[i] = ok;
             if (A_MASK) { r_mask[i] = p.a_mask[row]; }
         }
-        const float* wp = wrow + ld_tap * p.ktap + ld_c;
+        if constexpr (TERMS == 0) {
+            const float* wp = wrow + ld_tap * p.ktap + ld_c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * Kp);
+            for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * Kp);
+        } else {
+            const __bf16* wp = wrow16 + ld_tap * p.ktap + ld_c;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rw[pl][j] = *reinterpret_cast<const bf16x8*>(wp + pl * wplane + (size_t)(64 * j) * Kp);
+        }
         ld_c += GEMM_BK;
         if (ld_c >= p.ktap) { ld_c = 0; ++ld_tap; }
     };
     auto stage = [&](int buf) {
-        float* As = lds + buf * TILE_FLOATS;
-        float* Bs = As + BM * LDS_STRIDE;
+        if constexpr (TERMS == 0) {
+            float* As = lds + buf * TILE_FLOATS;
+            float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            f32x4 v = ra[i];
-            if (A_NORM) v = (v - r_mean[i]) * r_rstd[i];
-            if (A_MASK) v *= r_mask[i];
-            if (!r_ok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_STRIDE + lq) = v;
+            for (int i = 0; i < AR; ++i) {
+                f32x4 v = ra[i];
+                if (A_NORM) v = (v - r_mean[i]) * r_rstd[i];
+                if (A_MASK) v *= r_mask[i];
+                if (!r_ok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_STRIDE + lq) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lq) = rb[i];
+        } else {
+            __bf16* As = reinterpret_cast<__bf16*>(lds);
+            __bf16* Bs = As + NPL * APLANE;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                f32x4 v = ra[i];
+                if (A_NORM) v = (v - r_mean[i]) * r_rstd[i];
+                if (A_MASK) v *= r_mask[i];
+                if (!r_ok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
+                __bf16* d = As + (lrow + 32 * i) * SPLIT_RS + lq;
+                *reinterpret_cast<bf16x4*>(d) = h;
+                *reinterpret_cast<bf16x4*>(d + APLANE) = m;
+                if (NPL == 3) *reinterpret_cast<bf16x4*>(d + 2 * APLANE) = l;
+            }
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(Bs + pl * BPLANE + (wr16 + 64 * j) * SPLIT_RS + wc16) = rw[pl][j];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lq) = rb[i];
     };
 
     f32x16 acc[MI][2];
@@ -223,32 +290,67 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         }
     }
 
-    stage(0);
-    __syncthreads();
-
-    const int frag_off = (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) fetch();
-        const float* Aw = lds + (kt & 1) * TILE_FLOATS + (wm * (BM / 2)) * LDS_STRIDE + frag_off;
-        const float* Bw = lds + (kt & 1) * TILE_FLOATS + (BM + wn * 64) * LDS_STRIDE + frag_off;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 a[MI], b[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDS_STRIDE + 8 * g);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDS_STRIDE + 8 * g);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-        }
-        if (more) stage((kt + 1) & 1);
+    if constexpr (TERMS == 0) {
+        stage(0);
         __syncthreads();
+        const int frag_off = (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) fetch();
+            const float* Aw = lds + (kt & 1) * TILE_FLOATS + (wm * (BM / 2)) * LDS_STRIDE + frag_off;
+            const float* Bw = lds + (kt & 1) * TILE_FLOATS + (BM + wn * 64) * LDS_STRIDE + frag_off;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a[MI], b[2];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDS_STRIDE + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDS_STRIDE + 8 * g);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            }
+            if (more) stage((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // split mode: one LDS stage; the other resident workgroup of the CU covers the two barriers per k-step.
+        // Fragment of v_mfma_f32_32x32x16_bf16: lane (r = lane&31, h = lane>>5) holds k = 8h .. 8h+7 of a 16-wide k block.
+        const __bf16* As = reinterpret_cast<const __bf16*>(lds);
+        const int frag = (lane & 31) * SPLIT_RS + 8 * (lane >> 5);
+        const __bf16* Aw = As + (wm * (BM / 2)) * SPLIT_RS + frag;
+        const __bf16* Bw = As + NPL * APLANE + (wn * 64) * SPLIT_RS + frag;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt) __syncthreads();          // everyone finished reading the previous tile
+            stage(0);
+            __syncthreads();
+            if (kt + 1 < nk) fetch();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 a[NPL][MI], b[NPL][2];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(Aw + pl * APLANE + i * 32 * SPLIT_RS + kb * 16);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(Bw + pl * BPLANE + j * 32 * SPLIT_RS + kb * 16);
+                }
+#pragma unroll
+                for (int sum = NPL - 1; sum >= 0; --sum)      // plane-index sum: smallest products first
+#pragma unroll
+                    for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[sum - pa][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                      // the epilogue tile overwrites the stage
     }
 
     // ---- epilogue.  Accumulator map (32x32 tile): column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -319,11 +421,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, bool A_MASK, bool A_NORM>
+template <int BM, bool A_MASK, bool A_NORM, int TERMS>
 static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_f32_kernel<BM, A_MASK, A_NORM>;
-    constexpr int lds_bytes = gemm_lds_bytes(BM);
+    auto kern = gemm_f32_kernel<BM, A_MASK, A_NORM, TERMS>;
+    constexpr int lds_bytes = gemm_lds_bytes(BM, TERMS);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -335,18 +437,25 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BM>
+template <int BM, int TERMS>
 static hipError_t launch_bm(const GemmArgs& a, hipStream_t s) {
     const bool mk = a.a_mask != nullptr, nm = a.a_mean != nullptr || a.a_part != nullptr;
-    if (mk && nm) return launch_variant<BM, true, true>(a, s);
-    if (mk) return launch_variant<BM, true, false>(a, s);
-    if (nm) return launch_variant<BM, false, true>(a, s);
-    return launch_variant<BM, false, false>(a, s);
+    if (mk && nm) return launch_variant<BM, true, true, TERMS>(a, s);
+    if (mk) return launch_variant<BM, true, false, TERMS>(a, s);
+    if (nm) return launch_variant<BM, false, true, TERMS>(a, s);
+    return launch_variant<BM, false, false, TERMS>(a, s);
+}
+
+template <int BM>
+static hipError_t launch_terms(const GemmArgs& a, hipStream_t s) {
+    if (a.terms == 6) return launch_bm<BM, 6>(a, s);
+    if (a.terms == 3) return launch_bm<BM, 3>(a, s);
+    return launch_bm<BM, 0>(a, s);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // shape contract (the kernel indexes without further checks)
-    if (!a.a0 || !a.w || !a.out || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
+    if (!a.a0 || (!a.w && !a.w16) || !a.out || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
     if (a.ntaps < 1 || a.ntaps > MAX_TAPS) return hipErrorInvalidValue;
     if (a.ktap % GEMM_BK != 0 || a.ktap < a.c0 + a.c1) return hipErrorInvalidValue;
     if ((a.c0 & 3) || (a.c1 & 3) || (a.lda0 & 3) || (a.lda1 & 3)) return hipErrorInvalidValue;
@@ -358,6 +467,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if ((a.a_mean || a.a_part) && (a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0)) return hipErrorInvalidValue;
     if (a.stats_out && ((a.N & 63) || (a.ldc & 3) || (a.res && (a.ldr & 3)))) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
+    if (a.terms != 0 && a.terms != 3 && a.terms != 6) return hipErrorInvalidValue;
+    if (a.terms != 0 && !a.w16) return hipErrorInvalidValue;
     // Block-tile height: 256 CUs x 2 resident workgroups = 512 slots per round; pick the height whose grid wastes the
     // least of its last round (e.g. M=10240, N=1152: 720 tiles of 128 rows fill 70 % of two rounds, 1440 tiles of 64
     // rows fill 94 % of three).  The 64-row tile has half the A-fragment reuse, hence the small handicap.
@@ -370,8 +481,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     };
     static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();   // A/B runs only
     const int force = a.force_bm ? a.force_bm : env_bm;
-    if (force == 64 || (force == 0 && 0.97 * fill(64) > fill(128))) return launch_bm<64>(a, s);
-    return launch_bm<128>(a, s);
+    if (force == 64 || (force == 0 && 0.97 * fill(64) > fill(128))) return launch_terms<64>(a, s);
+    return launch_terms<128>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -391,6 +502,48 @@ void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT,
                 if (col_scale) v *= col_scale[c];
                 dst[(size_t)n * Kp + j * ktap + c] = v;
             }
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);        // inf / nan unchanged (top bits)
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// fp32 panel [Np][Kp] -> three bf16 planes [3][Np][Kp] with w = h + m + l exactly (host side, same arithmetic as split3)
+void split_panel_host(const float* panel, size_t n, uint16_t* planes) {
+    for (size_t i = 0; i < n; ++i) {
+        const float x = panel[i];
+        const uint16_t h = f32_to_bf16_rne(x);
+        const float r1 = x - bf16_to_f32(h);
+        const uint16_t m = f32_to_bf16_rne(r1);
+        const float r2 = r1 - bf16_to_f32(m);
+        planes[i] = h;
+        planes[n + i] = m;
+        planes[2 * n + i] = f32_to_bf16_rne(r2);
+    }
+}
+
+__global__ void split_panel_kernel(const float* __restrict__ panel, size_t n, __bf16* __restrict__ planes) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        __bf16 h, m, l;
+        split3(panel[i], h, m, l);
+        planes[i] = h;
+        planes[n + i] = m;
+        planes[2 * n + i] = l;
+    }
+}
+hipError_t launch_split_panel(const float* panel, size_t n, void* planes, hipStream_t s) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_panel_kernel, dim3(grid), dim3(256), 0, s, panel, n, static_cast<__bf16*>(planes));
+    return hipGetLastError();
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int C, int ntaps, int ktap, int Np, float* __restrict__ dst) {

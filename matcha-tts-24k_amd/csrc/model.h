@@ -16,6 +16,7 @@ const char* get_error();
 // One GEMM-ready weight panel inside the device image (offsets in floats).
 struct Panel {
     size_t w = 0, b = 0;
+    size_t w16 = 0;            // bf16 split planes [3][Np][Kp] (offset in floats), present when the context uses a split mode
     bool has_bias = false;
     int N = 0, C = 0, ntaps = 1, ktap = 0;
 };
@@ -74,6 +75,7 @@ struct mtts_ctx {
     std::vector<float> image;     // host staging of the packed device image
     float* d_image = nullptr;     // caller-owned device buffer
     bool packed = false, uploaded = false;
+    int gemm_terms = 6;           // 0: fp32 MFMA, 6 / 3: split-bf16 MFMA (MTTS_GEMM_TERMS; see gemm_f32.hip)
     mtts::DecW dec;
     mtts::EncW enc;
     // profiling

@@ -3,6 +3,7 @@
 #include "model.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace mtts {
@@ -114,6 +115,13 @@ struct Packer {
                 const std::vector<float>* col_shift = nullptr) {
         return panel_multi({wkey}, {bkey}, kind, N, C, ntaps, kT, tsel, col_scale, col_shift);
     }
+    // bf16 split planes of a finished fp32 panel (split modes only)
+    void add_planes(Panel& p) {
+        if (c->gemm_terms == 0) return;
+        const size_t n = (size_t)round_up(p.N, GEMM_BN) * p.ntaps * p.ktap;
+        p.w16 = alloc((3 * n + 1) / 2);
+        split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+    }
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
         Panel p;
@@ -124,6 +132,7 @@ struct Packer {
         p.b = alloc(Np);
         pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w]);
         if (bias) { p.has_bias = true; std::memcpy(&c->image[p.b], bias, N * sizeof(float)); }
+        add_planes(p);
         return p;
     }
     // several [N_i, C(,k)] tensors stacked along N into one panel (q|k|v, concatenated time MLPs)
@@ -159,6 +168,7 @@ struct Packer {
                 c->image[p.b + (size_t)part * N_each + n] = (float)acc;
             }
         }
+        add_planes(p);
         return p;
     }
 };
@@ -313,6 +323,7 @@ static int pack_all(mtts_ctx* c) {
                 c->image[p.b + D.res[i].tb_off + n] = (*b)[n];
             }
         }
+        if (P.ok) P.add_planes(p);
         D.tmlp = p;
     }
     if (!P.ok) { set_error(P.why); return -1; }
@@ -322,8 +333,18 @@ static int pack_all(mtts_ctx* c) {
 
 static inline const float* W(const mtts_ctx* c, size_t off) { return c->d_image + off; }
 
+// GEMM arithmetic of new contexts: 6 (default, fp32-equivalent on the bf16 matrix cores), 0 (native fp32 MFMA), 3 (opt-in)
+static int default_gemm_terms() {
+    const char* e = getenv("MTTS_GEMM_TERMS");
+    if (!e) return 6;
+    const int t = atoi(e);
+    return (t == 0 || t == 3 || t == 6) ? t : 6;
+}
+
 static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
     a.w = W(c, p.w);
+    a.terms = c->gemm_terms;
+    a.w16 = c->gemm_terms ? static_cast<const void*>(W(c, p.w16)) : nullptr;
     a.bias = p.has_bias ? W(c, p.b) : nullptr;
     a.N = p.N;
     a.ntaps = p.ntaps;
@@ -618,6 +639,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     if (!why.empty()) { set_error(why); return nullptr; }
     mtts_ctx* c = new mtts_ctx();
     c->cfg = g;
+    c->gemm_terms = default_gemm_terms();
     return c;
 }
 
@@ -899,25 +921,33 @@ int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_
 }
 
 // ------------------------------------------------------------------------------------------------ single kernels
-int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps) {
-    return (int64_t)round_up(N, GEMM_BN) * ntaps * round_up(C, GEMM_BK) * (int64_t)sizeof(float);
+int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps) {   // fp32 panel + three bf16 planes
+    const int64_t n = (int64_t)round_up(N, GEMM_BN) * ntaps * round_up(C, GEMM_BK);
+    return n * 4 + ((3 * n + 1) / 2) * 4 + 256;
 }
 
 int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride, int T_out,
                   const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_a_part, int a_nparts,
                   const float* d_w, void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
                   const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc, float* d_stats_out,
-                  void* stream) {
+                  int terms, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
-    if (d_w) HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));   // NULL: d_wpacked already packed
+    if (terms < 0) terms = default_gemm_terms();
+    if (terms != 0 && terms != 3 && terms != 6) { set_error("terms must be 0, 3 or 6"); return -1; }
+    const size_t npanel = (size_t)round_up(N, GEMM_BN) * ntaps * round_up(C, GEMM_BK);
+    float* planes = static_cast<float*>(d_wpacked) + ((npanel + 63) & ~size_t(63));
+    if (d_w) {   // NULL: d_wpacked already packed by an earlier call
+        HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));
+        HIP_OK(launch_split_panel(static_cast<const float*>(d_wpacked), npanel, planes, s));
+    }
     GemmArgs a;
     a.a0 = d_a; a.lda0 = lda; a.c0 = C; a.ktap = round_up(C, GEMM_BK); a.ntaps = ntaps;
     for (int j = 0; j < ntaps; ++j) a.tap_off[j] = h_tap_off ? h_tap_off[j] : 0;
     a.in_stride = in_stride; a.B = B; a.T_in = T_in; a.T_out = T_out;
     a.a_mask = d_a_mask; a.a_mean = d_a_mean; a.a_rstd = d_a_rstd; a.a_part = d_a_part; a.a_nparts = a_nparts;
     a.stats_out = d_stats_out;
-    a.w = static_cast<const float*>(d_wpacked); a.bias = d_bias; a.N = N; a.act = act; a.p0 = d_p0; a.p1 = d_p1;
+    a.w = static_cast<const float*>(d_wpacked); a.w16 = planes; a.terms = terms; a.bias = d_bias; a.N = N; a.act = act; a.p0 = d_p0; a.p1 = d_p1;
     a.res = d_res; a.ldr = ldr; a.out_mask = d_out_mask; a.out_scale = out_scale; a.out = d_out; a.ldc = ldc;
     a.out_T = T_out; a.out_stride = 1; a.out_off = 0;
     HIP_OK(launch_gemm(a, s));
@@ -1078,6 +1108,7 @@ mtts_vocos* mtts_vocos_create(int n_mels, int dim, int inter, int layers, int n_
         return nullptr;
     }
     mtts_vocos* v = new mtts_vocos();
+    v->base.gemm_terms = default_gemm_terms();
     v->n_mels = n_mels; v->dim = dim; v->inter = inter; v->layers = layers; v->n_fft = n_fft; v->hop = hop;
     return v;
 }

@@ -20,6 +20,12 @@ def hip():
     return sub("_hip")
 
 
+@pytest.fixture(params=[0, 6], ids=["fp32-mfma", "bf16x6"])
+def terms(request):
+    """GEMM arithmetic: native fp32 MFMA, or the fp32-equivalent three-term bf16 split (the library default)."""
+    return request.param
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -41,60 +47,60 @@ def conv_ref(a, w, bias, B, T, pad, stride=1):
 
 
 @pytest.mark.parametrize("B,T,C,N", [(3, 100, 384, 384), (2, 77, 200, 100), (1, 5, 64, 1), (4, 160, 1536, 384), (1, 130, 96, 288)])
-def test_linear_bias_residual(hip, B, T, C, N):
+def test_linear_bias_residual(hip, terms, B, T, C, N):
     a, w, b, r = rnd(B * T, C, seed=1), rnd(N, C, seed=2, scale=C ** -0.5), rnd(N, seed=3), rnd(B * T, N, seed=4)
     ref = F.linear(a.double(), w.double(), b.double()) + r.double()
-    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, res=r.cuda())
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, res=r.cuda(), terms=terms)
     close(out, ref, 2e-6 * math.sqrt(C))
 
 
-def test_large_grid_uses_128_row_tiles(hip):
+def test_large_grid_uses_128_row_tiles(hip, terms):
     """M x N big enough for the 128x128 block tile (small problems above run on the 64x128 variant)."""
     B, T, C, N = 8, 1000, 96, 1152
     a, w, b = rnd(B * T, C, seed=41), rnd(N, C, seed=42, scale=C ** -0.5), rnd(N, seed=43)
     ref = F.linear(a.double(), w.double(), b.double())
-    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T)
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=terms)
     close(out, ref, 2e-5)
     # implicit conv on the same tile shape, ragged mask
     w3 = rnd(N, C, 3, seed=44, scale=(3 * C) ** -0.5)
     lens = torch.tensor([T - 13 * i for i in range(B)])
     mask = (torch.arange(T)[None] < lens[:, None]).float().reshape(-1)
-    out = hip.gemm_f32(a.cuda(), w3.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda())
+    out = hip.gemm_f32(a.cuda(), w3.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), terms=terms)
     close(out, conv_ref(a * mask[:, None], w3, b, B, T, 1), 2e-5)
 
 
-def test_identity_asymmetric(hip):
+def test_identity_asymmetric(hip, terms):
     """A = I with an asymmetric W catches a transposed accumulator map."""
     n = 128
     a = torch.eye(n)
     w = torch.arange(n * n, dtype=torch.float32).view(n, n) / 1000.0
-    out = hip.gemm_f32(a.cuda(), w.cuda(), None, B=1, T_in=n)
+    out = hip.gemm_f32(a.cuda(), w.cuda(), None, B=1, T_in=n, terms=terms)
     assert torch.equal(out.cpu(), w.t().contiguous())
 
 
 @pytest.mark.parametrize("k,C,N,B,T", [(3, 64, 96, 2, 77), (5, 96, 160, 3, 50), (3, 200, 384, 2, 130), (5, 1152, 288, 1, 128)])
-def test_conv_same_with_mask(hip, k, C, N, B, T):
+def test_conv_same_with_mask(hip, terms, k, C, N, B, T):
     a, w, b = rnd(B * T, C, seed=5), rnd(N, C, k, seed=6, scale=(C * k) ** -0.5), rnd(N, seed=7)
     lens = torch.tensor([T - 7 * i for i in range(B)])
     mask = (torch.arange(T)[None] < lens[:, None]).float().reshape(-1)
     ref = conv_ref(a * mask[:, None], w, b, B, T, k // 2)
-    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda())
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), terms=terms)
     close(out, ref, 2e-6 * math.sqrt(C * k))
     # the same with relu / silu and an output mask
     for act, fn in ((1, torch.relu), (2, F.silu)):
-        out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), act=act, out_mask=mask.cuda())
+        out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), act=act, out_mask=mask.cuda(), terms=terms)
         close(out, fn(ref) * mask[:, None].double(), 2e-6 * math.sqrt(C * k))
 
 
-def test_conv_stride2(hip):
+def test_conv_stride2(hip, terms):
     B, T, C, N = 2, 50, 64, 64
     a, w, b = rnd(B * T, C, seed=8), rnd(N, C, 3, seed=9, scale=(3 * C) ** -0.5), rnd(N, seed=10)
     ref = conv_ref(a, w, b, B, T, 1, stride=2)
-    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, T_out=25, in_stride=2)
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, T_out=25, in_stride=2, terms=terms)
     close(out, ref, 2e-5)
 
 
-def test_layernorm_prologue_and_snake(hip):
+def test_layernorm_prologue_and_snake(hip, terms):
     B, T, C, N = 2, 90, 384, 1536
     a = rnd(B * T, C, seed=11) * 2 + 0.3
     w, b = rnd(N, C, seed=12, scale=C ** -0.5), rnd(N, seed=13)
@@ -108,11 +114,11 @@ def test_layernorm_prologue_and_snake(hip):
     h = F.linear((ad - mu[:, None]) / torch.sqrt(var + 1e-5)[:, None], w.double(), b.double())
     ae, ib = torch.exp(alpha), 1.0 / (torch.exp(beta) + 1e-9)
     ref = h + ib.double() * torch.sin(h * ae.double()) ** 2
-    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd, act=3, p0=ae.cuda(), p1=ib.cuda())
+    out = hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd, act=3, p0=ae.cuda(), p1=ib.cuda(), terms=terms)
     close(out, ref, 1e-5)
 
 
-def test_layernorm_stats_travel_through_epilogue(hip):
+def test_layernorm_stats_travel_through_epilogue(hip, terms):
     """GEMM 1 writes x = a.W1^T + res and leaves (mean, M2) partials of its 64-column slices; GEMM 2 merges them in its
     prologue as the LayerNorm of x.  Must equal the two-pass statistics of row_stats on x."""
     for B, T in ((2, 100), (8, 1000)):      # 64-row and 128-row block tiles
@@ -120,17 +126,29 @@ def test_layernorm_stats_travel_through_epilogue(hip):
         a, r = rnd(B * T, C, seed=51), rnd(B * T, C, seed=52) * 2 + 0.5
         w1, b1 = rnd(C, C, seed=53, scale=C ** -0.5), rnd(C, seed=54)
         w2, b2 = rnd(1152, C, seed=55, scale=C ** -0.5), rnd(1152, seed=56)
-        x, stats = hip.gemm_f32(a.cuda(), w1.cuda(), b1.cuda(), B=B, T_in=T, res=r.cuda(), stats_out=True)
+        x, stats = hip.gemm_f32(a.cuda(), w1.cuda(), b1.cuda(), B=B, T_in=T, res=r.cuda(), stats_out=True, terms=terms)
         xd = x.cpu().double()
         assert torch.allclose(stats[:, :, 0].cpu().double(), xd.view(B * T, 6, 64).mean(-1), atol=1e-5)
         mean, rstd = hip.row_stats(x)
-        y_ref = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd)
-        y = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_part=stats)
+        y_ref = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd, terms=terms)
+        y = hip.gemm_f32(x, w2.cuda(), b2.cuda(), B=B, T_in=T, a_part=stats, terms=terms)
         mu = xd.mean(1, keepdim=True)
         var = ((xd - mu) ** 2).mean(1, keepdim=True)
         ref = F.linear((xd - mu) / torch.sqrt(var + 1e-5), w2.double(), b2.double())
         close(y, ref, 1e-5)
         assert (y - y_ref).abs().max().item() < 2e-5
+
+
+def test_two_term_split_is_opt_in_and_looser(hip):
+    """terms=3 (two bf16 terms, three products): ~2^-17 per product -- documented, not the default."""
+    B, T, C, N = 2, 300, 384, 384
+    a, w, b = rnd(B * T, C, seed=61), rnd(N, C, seed=62, scale=C ** -0.5), rnd(N, seed=63)
+    ref = F.linear(a.double(), w.double(), b.double())
+    e3 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=3).cpu().double() - ref).abs().max().item()
+    e6 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=6).cpu().double() - ref).abs().max().item()
+    e0 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=0).cpu().double() - ref).abs().max().item()
+    assert e6 < 3 * e0 + 1e-6      # fp32-equivalent
+    assert e3 < 2e-4 and e3 > e6   # visibly looser, still small
 
 
 @pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0),

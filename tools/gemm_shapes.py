@@ -40,15 +40,18 @@ SHAPES = [  # name, B, T_in, T_out, C, ntaps, stride, N, mask, norm, act, res, c
 
 
 FUSED = False
+TERMS = -1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--terms", type=int, default=-1, help="0 fp32 MFMA, 6 / 3 split-bf16 MFMA, -1 library default")
     ap.add_argument("--fused-stats", action="store_true", help="LayerNorm stats via epilogue partials (as the decoder runs them)")
     args = ap.parse_args()
-    global FUSED
+    global FUSED, TERMS
     FUSED = args.fused_stats
+    TERMS = args.terms
     lib = hip.load()
     dev = torch.device("cuda")
     tot_t = tot_f = 0.0
@@ -76,7 +79,7 @@ def main():
         def launch(wptr):
             hip.check(lib.mtts_gemm_f32(hip.ptr(a), Cc, B, Ti, Cc, nt, taps, st, To, hip.ptr(mask), hip.ptr(mean) if not part_in else None, hip.ptr(rstd) if not part_in else None, hip.ptr(part) if part_in else None, part.shape[1] if part_in else 0, wptr,
                                         packed.data_ptr(), hip.ptr(bias), N, act, hip.ptr(p0), hip.ptr(p1), hip.ptr(r), N if res else 0,
-                                        None, 1.0, hip.ptr(out), N, hip.ptr(stats) if st_out else None, s))
+                                        None, 1.0, hip.ptr(out), N, hip.ptr(stats) if st_out else None, TERMS, s))
         launch(hip.ptr(w.contiguous()))
         for _ in range(3):
             launch(None)
