@@ -31,6 +31,12 @@ import torch.distributed as dist
 
 PKG = "matcha-tts-24k_amd"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense
+# GEMM arithmetic modes (csrc/gemm_f32.hip): MFMA products executed per fp32-equivalent multiply-accumulate
+GEMM_MODES = {0: ("f32", "v_mfma_f32_32x32x2_f32 on fp32 operands", 1, PEAK_F32_MFMA_TFLOPS),
+              2: ("f32 via 2-term f16 split (fp32 accumulate)", "v_mfma_f32_32x32x16_f16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS),
+              6: ("f32 via 3-term bf16 split (fp32 accumulate)", "v_mfma_f32_32x32x16_bf16, 6 products per MAC", 6, PEAK_16BIT_MFMA_TFLOPS),
+              3: ("f32 via 2-term bf16 split (fp32 accumulate, ~2^-17 per product)", "v_mfma_f32_32x32x16_bf16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS)}
 BATCH, N_TOKENS, N_STEPS_ODE, SOLVER = 32, 128, 10, "euler"
 
 
@@ -169,6 +175,7 @@ def main():
     frames = valid_per_utt * BATCH * world * args.steps
     t_pad = 2 * valid_per_utt
 
+    terms = model.hip.gemm_terms()
     roofline = None
     if rank == 0 and not args.no_events:
         # same steps again with a HIP event pair around every kernel launch, recorded on the launch stream
@@ -187,10 +194,14 @@ def main():
         hip.prof_enable(False)
         hip.prof_reset()
         achieved = fl_g / (ms_g * 1e-3) / 1e12
+        _, instr, products, hw_peak = GEMM_MODES[terms]
+        peak = hw_peak / products      # fp32-equivalent peak: every algorithmic MAC costs `products` MFMA MACs
         roofline = {
-            "bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA GEMM / implicit conv1d, all instantiations)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+            "bound": "mfma", "kernel": "gemm_f32_kernel (GEMM / implicit conv1d, all instantiations)",
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
+            "peak_basis": f"{hw_peak:.0f} TFLOP/s dense ({instr}) / {products}",
+            "mfma_executed_tflops": round(achieved * products, 1),
             "algorithmic_mb_per_launch": round(by_g / max(n_g, 1) / 1e6, 2),
             "launches_per_step": n_g // args.steps, "avg_launch_us": round(ms_g * 1e3 / max(n_g, 1), 2),
             "gflop_per_launch": round(fl_g / max(n_g, 1) / 1e9, 3),
@@ -211,7 +222,7 @@ def main():
             "metric": "mel-frames/s (100-bin, 24 kHz) end-to-end synthesise(), n_timesteps=10",
             "value": round(frames / el, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": GEMM_MODES[terms][0], "data": "synthetic",
             "config": {"workload": ("" if default_cfg else f"NON-DEFAULT batch={BATCH} {SOLVER}/{N_STEPS_ODE} variant of ") +
                                    "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
                                    "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "

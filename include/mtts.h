@@ -128,9 +128,10 @@ int mtts_cfm_solve(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const fl
  * (d_w = NULL: d_wpacked already holds the packed panel from an earlier call).
  * act: 0 none, 1 relu, 2 silu, 3 SnakeBeta with d_p0 = exp(alpha)[N], d_p1 = 1/(exp(beta)+1e-9)[N]
  * (reference transformer.py:61-77).  Epilogue: c = act(acc + bias); c *= out_mask[row]; c = c*out_scale + res[row][n].
- * terms: arithmetic of the products: 0 = v_mfma_f32_32x32x2_f32 (native fp32), 6 = fp32-equivalent on the bf16 matrix
- * cores (operands split into three exact bf16 terms, six products, fp32 accumulate), 3 = two-term split (opt-in),
- * -1 = the library default (6, or MTTS_GEMM_TERMS).
+ * terms: arithmetic of the products, all with fp32 accumulation: 0 = v_mfma_f32_32x32x2_f32 (native fp32);
+ * 2 = operands split into two fp16 terms with a 2^11-scaled residual (22 significand bits), three f16 MFMA products --
+ * measured error equals the fp32 chain's, inputs beyond +-65504 saturate; 6 = three exact bf16 terms, six bf16 MFMA
+ * products (full fp32 range); 3 = two bf16 terms (looser, opt-in); -1 = the library default (2, or MTTS_GEMM_TERMS).
  * LayerNorm prologue: either d_a_mean/d_a_rstd [rows], or d_a_part [rows][a_nparts][2] = (mean, M2) of 64-column slices
  * as written by a previous call's d_stats_out [M][N/64][2] (N % 64 == 0).  All optional pointers may be NULL. */
 int64_t mtts_gemm_packed_bytes(int N, int C, int ntaps);
@@ -173,6 +174,10 @@ int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_
                       void* stream);
 
 /* ---------------------------------------------------------------- measurement */
+
+/* GEMM arithmetic of a context (NULL: the library default): 0 native fp32 MFMA, 2 fp16 two-term split (default),
+ * 6 bf16 three-term split, 3 bf16 two-term split -- see mtts_gemm_f32. */
+int mtts_gemm_terms(mtts_ctx* ctx);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline line).
  * Classes: 0 gemm, 1 attention, 2 norm/activation/elementwise. */

@@ -98,6 +98,7 @@ def load() -> C.CDLL:
         "mtts_vocos_upload_weights": (i32, [vp, vp, i64]),
         "mtts_vocos_workspace_bytes": (i64, [vp, i32, i32]),
         "mtts_vocos_decode": (i32, [vp, vp, i32, i32, vp, vp, i64, vp]),
+        "mtts_gemm_terms": (i32, [vp]),
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
         "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -301,6 +302,9 @@ class HipModel:
         return out
 
     # ------------------------------------------------------------------ measurement
+    def gemm_terms(self) -> int:
+        return self.lib.mtts_gemm_terms(self.ctx)
+
     def prof_enable(self, on: bool) -> None:
         check(self.lib.mtts_prof_enable(self.ctx, int(on)))
 

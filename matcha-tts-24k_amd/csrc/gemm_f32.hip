@@ -23,7 +23,12 @@
 //      2^-24 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (products of bf16 values are exact in fp32).  The
 //      dropped products are below fp32 rounding, so the result differs from the fp32 chain by summation order only
 //      (measured: same error vs fp64), at 6/16 of the fp32-MFMA cycles.
-//   3  two-term split, three products (weights above 2^-16): ~2^-17 relative per product; opt-in.
+//   3  two-term bf16 split, three products (weights above 2^-16): ~2^-17 relative per product; opt-in.
+//   2  two-term fp16 split with a scaled residual: x ~ h + l/2^11, h = fp16(x), l = fp16((x - h) * 2^11) (22 significand
+//      bits; the scaling keeps the residual out of the fp16 subnormal range), products h.h into one accumulator and
+//      h.l + l.h into a second one that is folded in with 2^-11 in the epilogue: three v_mfma_f32_32x32x16_f16 per 16-k
+//      block (3/16 of the fp32-MFMA cycles).  Measured error vs fp64 equals the fp32 chain's.  Inputs beyond the fp16
+//      range (|x| > 65504) saturate instead of overflowing.
 #include "kernels.h"
 
 #include <cstdlib>
@@ -35,6 +40,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int LDS_STRIDE = GEMM_BK + 4;                              // 36 floats = 144 B (9 x 16 B)
 // one (A,B) stage of a BM x 128 block tile; two stages: BM=128 -> 73,728 B, BM=64 -> 55,296 B (2 workgroups per CU)
@@ -44,12 +51,18 @@ constexpr int tile_floats(int BM) { return (BM + GEMM_BN) * LDS_STRIDE; }
 // (4 waves x BM/2 rows x 68 floats) reuses the same LDS and is the larger of the two at BM = 128.
 constexpr int SPLIT_RS = 40;                                         // row stride in bf16 elements
 constexpr int split_planes(int terms) { return terms == 6 ? 3 : 2; }
+constexpr float F16_RES_SCALE = 2048.0f;                              // TERMS = 2: residual stored times 2^11
 constexpr int epi_bytes(int BM) { return 4 * (BM / 2) * 68 * 4; }
 constexpr int gemm_lds_bytes(int BM, int terms) {
     const int stage = terms == 0 ? 2 * tile_floats(BM) * 4 : split_planes(terms) * (BM + GEMM_BN) * SPLIT_RS * 2;
     return stage > epi_bytes(BM) ? stage : epi_bytes(BM);
 }
 
+__device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
+    const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
+    h = (_Float16)xc;
+    l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
+}
 // x = h + m + l exactly (three round-to-nearest bf16 terms of 8 significand bits each; the subtractions are exact)
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -219,13 +232,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
                 if (A_NORM) v = (v - r_mean[i]) * r_rstd[i];
                 if (A_MASK) v *= r_mask[i];
                 if (!r_ok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                bf16x4 h, m, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
                 __bf16* d = As + (lrow + 32 * i) * SPLIT_RS + lq;
-                *reinterpret_cast<bf16x4*>(d) = h;
-                *reinterpret_cast<bf16x4*>(d + APLANE) = m;
-                if (NPL == 3) *reinterpret_cast<bf16x4*>(d + 2 * APLANE) = l;
+                if constexpr (TERMS == 2) {
+                    f16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(v[e], a, b); h[e] = a; l[e] = b; }
+                    *reinterpret_cast<f16x4*>(d) = h;
+                    *reinterpret_cast<f16x4*>(d + APLANE) = l;
+                } else {
+                    bf16x4 h, m, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
+                    *reinterpret_cast<bf16x4*>(d) = h;
+                    *reinterpret_cast<bf16x4*>(d + APLANE) = m;
+                    if (NPL == 3) *reinterpret_cast<bf16x4*>(d + 2 * APLANE) = l;
+                }
             }
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
@@ -234,6 +255,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         }
     };
 
+    f32x16 accx[TERMS == 2 ? MI : 1][2];      // TERMS = 2: cross products (scaled by 2^11)
+    if constexpr (TERMS == 2) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+    }
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -339,15 +369,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(Bw + pl * BPLANE + j * 32 * SPLIT_RS + kb * 16);
                 }
+                if constexpr (TERMS == 2) {
 #pragma unroll
-                for (int sum = NPL - 1; sum >= 0; --sum)      // plane-index sum: smallest products first
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int pa = 0; pa <= sum; ++pa)
+                        for (int j = 0; j < 2; ++j) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, a[0][i]), al = __builtin_bit_cast(f16x8, a[1][i]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, b[0][j]), bl = __builtin_bit_cast(f16x8, b[1][j]);
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[i][j], 0, 0, 0);
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                        }
+                } else {
 #pragma unroll
-                        for (int i = 0; i < MI; ++i)
+                    for (int sum = NPL - 1; sum >= 0; --sum)      // plane-index sum: smallest products first
 #pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[sum - pa][j], acc[i][j], 0, 0, 0);
+                        for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[sum - pa][j], acc[i][j], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                      // the epilogue tile overwrites the stage
@@ -364,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + j * 32 + (lane & 31)] = acc[i][j][r];
+                Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + j * 32 + (lane & 31)] =
+                    (TERMS == 2) ? acc[i][j][r] + accx[i][j][r] * (1.0f / F16_RES_SCALE) : acc[i][j][r];
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave, no barrier needed
     __builtin_amdgcn_wave_barrier();
 
@@ -450,6 +494,7 @@ template <int BM>
 static hipError_t launch_terms(const GemmArgs& a, hipStream_t s) {
     if (a.terms == 6) return launch_bm<BM, 6>(a, s);
     if (a.terms == 3) return launch_bm<BM, 3>(a, s);
+    if (a.terms == 2) return launch_bm<BM, 2>(a, s);
     return launch_bm<BM, 0>(a, s);
 }
 
@@ -467,7 +512,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if ((a.a_mean || a.a_part) && (a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0)) return hipErrorInvalidValue;
     if (a.stats_out && ((a.N & 63) || (a.ldc & 3) || (a.res && (a.ldr & 3)))) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
-    if (a.terms != 0 && a.terms != 3 && a.terms != 6) return hipErrorInvalidValue;
+    if (a.terms != 0 && a.terms != 2 && a.terms != 3 && a.terms != 6) return hipErrorInvalidValue;
     if (a.terms != 0 && !a.w16) return hipErrorInvalidValue;
     // Block-tile height: 256 CUs x 2 resident workgroups = 512 slots per round; pick the height whose grid wastes the
     // least of its last round (e.g. M=10240, N=1152: 720 tiles of 128 rows fill 70 % of two rounds, 1440 tiles of 64
@@ -527,6 +572,34 @@ void split_panel_host(const float* panel, size_t n, uint16_t* planes) {
         planes[i] = h;
         planes[n + i] = m;
         planes[2 * n + i] = f32_to_bf16_rne(r2);
+    }
+}
+
+// TERMS = 2 planes: [h | l] fp16 with the scaled residual (same arithmetic as split_f16)
+__global__ void split_panel_f16_kernel(const float* __restrict__ panel, size_t n, _Float16* __restrict__ planes) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        _Float16 h, l;
+        split_f16(panel[i], h, l);
+        planes[i] = h;
+        planes[n + i] = l;
+    }
+}
+hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hipStream_t s) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_panel_f16_kernel, dim3(grid), dim3(256), 0, s, panel, n, static_cast<_Float16*>(planes));
+    return hipGetLastError();
+}
+void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes) {
+    for (size_t i = 0; i < n; ++i) {
+        const float x = panel[i];
+        const float xc = x < -65504.f ? -65504.f : (x > 65504.f ? 65504.f : x);
+        const _Float16 h = (_Float16)xc;
+        float r = (x - (float)h) * F16_RES_SCALE;
+        r = r < -65504.f ? -65504.f : (r > 65504.f ? 65504.f : r);
+        const _Float16 l = (_Float16)r;
+        memcpy(&planes[i], &h, 2);
+        memcpy(&planes[n + i], &l, 2);
     }
 }
 

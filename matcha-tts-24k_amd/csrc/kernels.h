@@ -36,7 +36,7 @@ struct GemmArgs {
     // ---- B operand: packed [Np][Kp], Np = round_up(N,128), Kp = ntaps * ktap
     const float* w = nullptr;
     const void* w16 = nullptr;        // split modes: bf16 planes [3][Np][Kp] of the same panel (w = h + m + l)
-    int terms = 0;                    // 0: fp32 MFMA; 6 / 3: bf16 MFMA on split operands (see gemm_f32.hip)
+    int terms = 0;                    // 0: fp32 MFMA; 6 / 3: bf16 MFMA, 2: fp16 MFMA on split operands (see gemm_f32.hip)
     const float* bias = nullptr;      // [Np] or null
     int N = 0;
     // ---- epilogue: c = act(acc + bias); c *= out_mask[row]; c = c * out_scale + res[row][n]
@@ -71,6 +71,8 @@ void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT,
 hipError_t launch_pack_weight(const float* w, int N, int C, int ntaps, float* dst, hipStream_t s);
 void split_panel_host(const float* panel, size_t n, uint16_t* planes);
 hipError_t launch_split_panel(const float* panel, size_t n, void* planes, hipStream_t s);
+void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes);
+hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hipStream_t s);
 
 struct AttnArgs {
     const float* qkv = nullptr;   // [B*T, 3*H*D]

@@ -120,7 +120,8 @@ struct Packer {
         if (c->gemm_terms == 0) return;
         const size_t n = (size_t)round_up(p.N, GEMM_BN) * p.ntaps * p.ktap;
         p.w16 = alloc((3 * n + 1) / 2);
-        split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+        if (c->gemm_terms == 2) split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+        else split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
     }
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
@@ -333,12 +334,13 @@ static int pack_all(mtts_ctx* c) {
 
 static inline const float* W(const mtts_ctx* c, size_t off) { return c->d_image + off; }
 
-// GEMM arithmetic of new contexts: 6 (default, fp32-equivalent on the bf16 matrix cores), 0 (native fp32 MFMA), 3 (opt-in)
+// GEMM arithmetic of new contexts (gemm_f32.hip): 2 (default) fp16 two-term split with scaled residual, 6 bf16 three-term
+// split (both fp32-equivalent), 0 native fp32 MFMA, 3 bf16 two-term split (looser, opt-in).  MTTS_GEMM_TERMS overrides.
 static int default_gemm_terms() {
     const char* e = getenv("MTTS_GEMM_TERMS");
-    if (!e) return 6;
+    if (!e) return 2;
     const int t = atoi(e);
-    return (t == 0 || t == 3 || t == 6) ? t : 6;
+    return (t == 0 || t == 2 || t == 3 || t == 6) ? t : 2;
 }
 
 static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
@@ -934,12 +936,13 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
     if (terms < 0) terms = default_gemm_terms();
-    if (terms != 0 && terms != 3 && terms != 6) { set_error("terms must be 0, 3 or 6"); return -1; }
+    if (terms != 0 && terms != 2 && terms != 3 && terms != 6) { set_error("terms must be 0, 2, 3 or 6"); return -1; }
     const size_t npanel = (size_t)round_up(N, GEMM_BN) * ntaps * round_up(C, GEMM_BK);
     float* planes = static_cast<float*>(d_wpacked) + ((npanel + 63) & ~size_t(63));
     if (d_w) {   // NULL: d_wpacked already packed by an earlier call
         HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));
-        HIP_OK(launch_split_panel(static_cast<const float*>(d_wpacked), npanel, planes, s));
+        if (terms == 2) HIP_OK(launch_split_panel_f16(static_cast<const float*>(d_wpacked), npanel, planes, s));
+        else HIP_OK(launch_split_panel(static_cast<const float*>(d_wpacked), npanel, planes, s));
     }
     GemmArgs a;
     a.a0 = d_a; a.lda0 = lda; a.c0 = C; a.ktap = round_up(C, GEMM_BK); a.ntaps = ntaps;
@@ -981,6 +984,8 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
 }
 
 // ------------------------------------------------------------------------------------------------ measurement
+int mtts_gemm_terms(mtts_ctx* c) { return c ? c->gemm_terms : default_gemm_terms(); }
+
 int mtts_prof_enable(mtts_ctx* c, int on) {
     if (!c) { set_error("null context"); return -1; }
     c->prof_on = on != 0;

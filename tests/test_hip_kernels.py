@@ -20,9 +20,10 @@ def hip():
     return sub("_hip")
 
 
-@pytest.fixture(params=[0, 6], ids=["fp32-mfma", "bf16x6"])
+@pytest.fixture(params=[0, 6, 2], ids=["fp32-mfma", "bf16x6", "f16x3s"])
 def terms(request):
-    """GEMM arithmetic: native fp32 MFMA, or the fp32-equivalent three-term bf16 split (the library default)."""
+    """GEMM arithmetic: native fp32 MFMA, the three-term bf16 split, or the two-term fp16 split with scaled residual
+    (all fp32-equivalent; see gemm_f32.hip)."""
     return request.param
 
 
@@ -75,7 +76,10 @@ def test_identity_asymmetric(hip, terms):
     a = torch.eye(n)
     w = torch.arange(n * n, dtype=torch.float32).view(n, n) / 1000.0
     out = hip.gemm_f32(a.cuda(), w.cuda(), None, B=1, T_in=n, terms=terms)
-    assert torch.equal(out.cpu(), w.t().contiguous())
+    if terms == 2:      # 22 significand bits per operand: not bit-exact, but far below any transposition error
+        assert (out.cpu() - w.t()).abs().max().item() < 1e-5
+    else:
+        assert torch.equal(out.cpu(), w.t().contiguous())
 
 
 @pytest.mark.parametrize("k,C,N,B,T", [(3, 64, 96, 2, 77), (5, 96, 160, 3, 50), (3, 200, 384, 2, 130), (5, 1152, 288, 1, 128)])
@@ -147,7 +151,15 @@ def test_two_term_split_is_opt_in_and_looser(hip):
     e3 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=3).cpu().double() - ref).abs().max().item()
     e6 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=6).cpu().double() - ref).abs().max().item()
     e0 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=0).cpu().double() - ref).abs().max().item()
+    e2 = (hip.gemm_f32(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, terms=2).cpu().double() - ref).abs().max().item()
     assert e6 < 3 * e0 + 1e-6      # fp32-equivalent
+    assert e2 < 3 * e0 + 1e-6      # fp32-equivalent
+    # fp16 split: tiny and huge operands (subnormal residuals are avoided by the 2^11 scaling; beyond 65504 saturates, no inf)
+    small = hip.gemm_f32((a * 1e-4).cuda(), (w * 1e-3).cuda(), None, B=B, T_in=T, terms=2).cpu().double()
+    ref_s = F.linear((a * 1e-4).double(), (w * 1e-3).double())
+    assert (small - ref_s).abs().max().item() < 1e-5 * ref_s.abs().max().item()
+    big = a.clone(); big[0, 0] = 1e6
+    assert torch.isfinite(hip.gemm_f32(big.cuda(), w.cuda(), None, B=B, T_in=T, terms=2)).all()
     assert e3 < 2e-4 and e3 > e6   # visibly looser, still small
 
 
