@@ -218,7 +218,7 @@ class HipModel:
         self._ws.clear()
 
     def _workspace(self, kind: str, a: int, b: int) -> torch.Tensor:
-        key = (kind, a, b)
+        key = (kind, a, b, stream_ptr())      # one workspace per stream: concurrent calls on different streams must not share scratch
         ws = self._ws.get(key)
         if ws is None:
             fn = self.lib.mtts_decoder_workspace_bytes if kind == "dec" else self.lib.mtts_encoder_workspace_bytes

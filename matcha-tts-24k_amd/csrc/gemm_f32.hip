@@ -122,8 +122,10 @@ __device__ __forceinline__ float allreduce8(float v) {
 
 __device__ __forceinline__ int round_up_dev(int n) { return (n + GEMM_BN - 1) / GEMM_BN * GEMM_BN; }
 
+// Registers: the 64-row split-mode tile is held to 168 VGPRs (3 waves per SIMD = 3 workgroups per CU; its LDS footprint
+// of 35 KB allows 4) -- with the short 16-bit MFMA phases more resident workgroups hide the staging better.
 template <int BM, bool A_MASK, bool A_NORM, int TERMS>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f32_kernel(const GemmArgs p) {
     constexpr int MI = BM / 64;                 // 32-row MFMA tiles per wave along M
     constexpr int AR = BM / 32;                 // A rows staged per thread
     constexpr int TILE_FLOATS = tile_floats(BM);
