@@ -6,9 +6,15 @@
 //   encoder: F.scaled_dot_product_attention with a boolean query*key mask (reference text_encoder.py:228-235,306)
 //
 // Work split: one workgroup per (batch, head, block of 128 or 64 queries), each of its 4 or 2 waves 32 of them.  Keys/values stream through LDS in tiles of 64 (global -> registers prefetch -> LDS).
-// Both products run on v_mfma_f32_32x32x2_f32 in the "transposed" orientation so that the query sits on the lane:
+// Both products run in the "transposed" orientation so that the query sits on the lane:
 //   S^T[key][q] = K[key][:] . Q[q][:]     A = K fragment (LDS, ds_read_b128), B = Q fragment (registers, loaded once)
 //   O^T[d][q]  += V^T[d][key] . P^T[key][q]   A = V column (LDS, ds_read_b32), B = the S^T accumulator itself
+// Both run on the f16 matrix pipe with split operands (x = h + l, h = fp16(x), l = fp16(x - h); products h.h + h.l + l.h,
+// fp32 accumulate: 3 v_mfma_f32_32x32x16_f16 per 16-deep block instead of 8 v_mfma_f32_32x32x2_f32).  q, k, v are O(1)
+// and p <= 1, so the residuals stay representable (absolute error ~3e-8 per operand); the softmax scale multiplies the
+// fp32 scores.  The S^T accumulator feeds P.V without leaving registers: registers 8s..8s+7 of a 32-key sub-tile are the
+// B fragment of key block s in the permuted key order 16s + 8(j>>2) + 4h + (j&3), and V is staged TRANSPOSED ([d][key])
+// so that the matching A fragment is two 8-byte LDS reads.
 // so the softmax row (max, sum) is a reduction over the lane's own registers plus one cross-half shuffle, the
 // probabilities never leave registers, and the per-query rescale is a lane-uniform multiply of the O^T accumulators.
 // Head dims below 64 (encoder: 48) are zero-padded to 64 in the staged tiles.
@@ -18,11 +24,14 @@ namespace mtts {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int AT_QW = 32;     // queries per wave (one 32-column MFMA tile)
 constexpr int AT_K = 64;      // keys per tile
 constexpr int AT_D = 64;      // padded head dim
-constexpr int AT_S = 68;      // LDS row stride (floats): 17 x 16 B, conflict-free b128 row reads
+constexpr int AT_VS = 68;     // LDS row stride of a V^T plane (halves): 136 B, conflict-free 8-byte column-group reads
+constexpr int AT_KS = 72;     // LDS row stride of a K plane (halves): 144 B = 9 x 16 B, conflict-free 16-byte fragment reads
 constexpr float NEG_BIG = -1e30f;
 constexpr float LOG2E = 1.44269504088896340736f;
 // exp(x) for x <= 0 as one v_exp_f32 (2^t, ~1 ulp) after an exact-to-rounding scale by log2(e): the softmax weights
@@ -36,8 +45,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
     constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
-    __shared__ __attribute__((aligned(16))) float Ks[AT_K * AT_S];
-    __shared__ __attribute__((aligned(16))) float Vs[AT_K * AT_S];
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2 * AT_K * AT_KS];   // planes h | l
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[2 * AT_D * AT_VS];   // V^T planes h | l: [d][key]
     __shared__ __attribute__((aligned(16))) float Bs[AT_K];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,18 +70,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     const float* vptr = p.qkv + 2 * p.H * p.D + head * p.D;
     const float ninf = -__builtin_huge_valf();
 
-    // ---- Q fragment: lane (q = lq, half h) holds Q[q][8g + 4h + kk] * scale, g < 8, kk < 4
+    // ---- Q fragments for v_mfma_f32_32x32x16_f16 (B operand): lane (q = lq, half h) holds Q[q][16kb + 8h + j], j < 8,
+    // kb < 4, as two fp16 terms (unscaled; the softmax scale multiplies the fp32 scores)
     const int qi = q0 + lq;
     const bool q_in = qi < p.T;
     bool q_ok = q_in;
     if (p.mask_mode == 1 && q_in) q_ok = p.mask[rowbase + qi] != 0.f;
-    f32x4 qf[8];
+    f16x8 qh[4], ql[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int d = 8 * g + 4 * h;
-        if (q_in && d < p.D) v = *reinterpret_cast<const f32x4*>(qptr + (rowbase + qi) * ld + d);
-        qf[g] = v * p.scale;
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int half4 = 0; half4 < 2; ++half4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int d = 16 * kb + 8 * h + 4 * half4;
+            if (q_in && d < p.D) v = *reinterpret_cast<const f32x4*>(qptr + (rowbase + qi) * ld + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 a = (_Float16)v[e];
+                qh[kb][4 * half4 + e] = a;
+                ql[kb][4 * half4 + e] = (_Float16)(v[e] - (float)a);
+            }
+        }
     }
 
     f32x16 o[2];
@@ -113,8 +131,23 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const bool ok = r_in[sp] && (sd + 16 * c) < p.D;
-                *reinterpret_cast<f32x4*>(Ks + r * AT_S + sd + 16 * c) = ok ? rk[sp][c] : zero;
-                *reinterpret_cast<f32x4*>(Vs + r * AT_S + sd + 16 * c) = ok ? rv[sp][c] : zero;
+                const f32x4 kv = ok ? rk[sp][c] : zero;
+                f16x4 kh, kl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 a = (_Float16)kv[e];
+                    kh[e] = a;
+                    kl[e] = (_Float16)(kv[e] - (float)a);
+                }
+                *reinterpret_cast<f16x4*>(Ks + r * AT_KS + sd + 16 * c) = kh;
+                *reinterpret_cast<f16x4*>(Ks + AT_K * AT_KS + r * AT_KS + sd + 16 * c) = kl;
+                const f32x4 vv = ok ? rv[sp][c] : zero;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // transposing 16-bit stores: Vt[d][key]
+                    const _Float16 a = (_Float16)vv[e];
+                    Vt[(sd + 16 * c + e) * AT_VS + r] = a;
+                    Vt[AT_D * AT_VS + (sd + 16 * c + e) * AT_VS + r] = (_Float16)(vv[e] - (float)a);
+                }
             }
             if ((tid & 3) == 0) {
                 float bv = ninf;
@@ -132,19 +165,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         __syncthreads();
         if (kt + 1 < ntiles) fetch((kt + 1) * AT_K);
 
-        // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys
+        // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys (A = K fragment: lane (key, h) holds K[key][16kb + 8h + j])
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-            const float* kp = Ks + (32 * t + lq) * AT_S + 4 * h;
+            const _Float16* kp = Ks + (32 * t + lq) * AT_KS + 8 * h;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * g);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kk], qf[g][kk], s[t], 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kp + 16 * kb);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + AT_K * AT_KS + 16 * kb);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], s[t], 0, 0, 0);
             }
         }
         // ---- bias + online softmax.  Register r of sub-tile t is key 32t + (r&3) + 8(r>>2) + 4h.
@@ -156,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + 32 * t + 8 * g4 + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = q_ok ? s[t][4 * g4 + e] + bb[e] : ninf;
+                    float v = q_ok ? s[t][4 * g4 + e] * p.scale + bb[e] : ninf;
                     s[t][4 * g4 + e] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -179,16 +213,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        // ---- O^T += V^T . P^T
+        // ---- O^T += V^T . P^T on split f16 operands
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v0 = Vs[key * AT_S + lq];
-                const float v1 = Vs[key * AT_S + 32 + lq];
-                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[t][r], o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[t][r], o[1], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = s[t][8 * ks + j];
+                    const _Float16 a = (_Float16)pv;
+                    ph[j] = a;
+                    pl[j] = (_Float16)(pv - (float)a);
+                }
+                const int k0 = 32 * t + 16 * ks + 4 * h;       // this lane half's keys: k0..k0+3 and k0+8..k0+11
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const _Float16* vp = Vt + (32 * dt + lq) * AT_VS + k0;
+                    f16x8 vh, vl;
+                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(vp), h1 = *reinterpret_cast<const f16x4*>(vp + 8);
+                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(vp + AT_D * AT_VS), l1 = *reinterpret_cast<const f16x4*>(vp + AT_D * AT_VS + 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
+                }
             }
     }
 

@@ -13,7 +13,7 @@ hp = hp_m.prod_v20(1); sd = syn.make_state_dict(hp)
 m = inf.MatchaTTSInfer(**hp.as_reference_kwargs()); m.load_state_dict(sd); m = m.to(dev).eval()
 g = np.load(ROOT / "tests/golden/prod_synth.npz")
 x, xl, _ = syn.make_inputs(hp, 1, 128); z = syn.cpu_noise((1, 100, 640)).to(dev)
-out = [f"MTTS_GEMM_TERMS={os.environ.get('MTTS_GEMM_TERMS', '6 (default)')}"]
+out = [f"GEMM arithmetic mode (terms) = {m.hip.gemm_terms()}"]
 for solver, steps, key in (("euler", 2, "mel_euler2"), ("euler", 10, "mel_euler10"), ("midpoint", 4, "mel_midpoint4")):
     m.decoder.solver = solver
     mel = m.synthesise(x.to(dev), xl.to(dev), steps, speaker=0, z=z)["mel"].cpu()
