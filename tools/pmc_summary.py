@@ -54,7 +54,19 @@ def main():
         if k.startswith("gemm_f32_kernel"):
             g_bytes += (rd + wr) * n
             g_n += n
-    summary = {"tag": tag, "command": "python3 bench.py --steps N --warmup 1 --no-cpu-baseline --no-events (under rocprofv3)",
+    # MFMA-pipe busy fraction per kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024)
+    mfma = []
+    mf_files = glob.glob(str(src / "mfma" / "*" / "*_counter_collection.csv"))
+    if mf_files:
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for f in mf_files:
+            for r in csv.DictReader(open(f)):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
+            gui, busy = v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            if busy > 0 and gui > 0:
+                mfma.append({"kernel": k, "mfma_busy_fraction": round(busy / (gui / 8.0 * 1024.0), 4)})
+    summary = {"tag": tag, "mfma_busy": mfma, "command": "python3 bench.py --steps N --warmup 1 --no-cpu-baseline --no-events (under rocprofv3)",
                "corrections": "FETCH_SIZE x2 (gfx950), KiB -> bytes x1024", "gemm_hbm_mb_per_launch": round(g_bytes / max(g_n, 1) / 1e6, 2),
                "gemm_launches": g_n, "kernels": rows[:16]}
     (out / f"{tag}_pmc_traffic.json").write_text(json.dumps(summary, indent=1))

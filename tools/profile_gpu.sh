@@ -11,3 +11,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events > $OUT/fetch_bench.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events > $OUT/write_bench.json 2> $OUT/write.err
 echo "profiles in $OUT"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events > $OUT/mfma_bench.json 2> $OUT/mfma.err || true
