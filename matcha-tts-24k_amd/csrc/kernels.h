@@ -114,6 +114,7 @@ struct GnApplyArgs {
     const float* chbias = nullptr;    // [C] (time-embedding bias of the ResNet block) or null
     const float* res = nullptr; int ldr = 0;
     float* out = nullptr;
+    float* stats_out = nullptr;       // [B*T][C/64][2] LayerNorm partial moments of the output rows (C % 64 == 0)
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

@@ -182,6 +182,15 @@ hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* 
     return hipGetLastError();
 }
 
+#define GN_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ float gn_allreduce16(float v) {   // all-reduce over a 16-lane DPP row
+    v = GN_DPP_ADD(v, 0x140);
+    v = GN_DPP_ADD(v, 0x141);
+    v = GN_DPP_ADD(v, 0x1B);
+    v = GN_DPP_ADD(v, 0xB1);
+    return v;
+}
+
 __global__ void gn_apply_kernel(const GnApplyArgs p) {
     __shared__ float smean[64], srstd[64];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
@@ -221,6 +230,17 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
         if (p.chbias) o = (o + cb) * mk;
         if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + c4 * 4);
         *reinterpret_cast<f32x4*>(p.out + row * p.C + c4 * 4) = o;
+        if (p.stats_out) {   // LayerNorm partial moments of the row's 64-column slices (16 threads = one DPP row each), as the
+                             // GEMM epilogue leaves them (gemm_f32.hip): the first transformer block needs no row_stats pass
+            const float mean = gn_allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
+            const f32x4 d = o - mean;
+            const float m2 = gn_allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+            if ((c4 & 15) == 0) {
+                float* so = p.stats_out + (row * (size_t)(p.C >> 6) + (c4 >> 4)) * 2;
+                so[0] = mean;
+                so[1] = m2;
+            }
+        }
     }
 }
 
@@ -228,6 +248,8 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     if (!a.y || !a.partial || !a.gamma || !a.beta || !a.mask || !a.out || a.B <= 0 || a.T <= 0 || !gn_shape_ok(a.C, a.G) ||
         (a.res && (a.ldr & 3)))
         return hipErrorInvalidValue;
+    // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
+    if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.T), a.B), gn_block(a.C), 0, s, a);
     return hipGetLastError();
 }
