@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
     const int wr16 = tid >> 2, wc16 = (tid & 3) * 8;
     const size_t wplane = (size_t)round_up_dev(p.N) * Kp;
     const __bf16* wrow16 = reinterpret_cast<const __bf16*>(p.w16) + (size_t)(n0 + wr16) * Kp + wc16;
+    // TERMS = 2: interleaved image [Np][Kp/32][h 32 | l 32]; a thread stages rows (tid>>3) + 32 j, 16-B chunk tid&7 of the line
+    const int wr8 = tid >> 3, wc8 = tid & 7;
+    const __bf16* wrow8 = reinterpret_cast<const __bf16*>(p.w16) + (size_t)(n0 + wr8) * Kp * 2 + wc8 * 8;
 
     // Tile fetch: every load is issued unconditionally (out-of-range rows read row 0 and are zeroed later), no load
     // depends on another load's result, and the mask / LayerNorm transform is deferred to the LDS write -- so the 8-20
@@ -201,6 +204,10 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
             const float* wp = wrow + ld_tap * p.ktap + ld_c;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * Kp);
+        } else if constexpr (TERMS == 2) {
+            const __bf16* wp = wrow8 + (ld_tap * p.ktap + ld_c) * 2;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rw[jj >> 1][jj & 1] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(32 * jj) * Kp * 2);
         } else {
             const __bf16* wp = wrow16 + ld_tap * p.ktap + ld_c;
 #pragma unroll
@@ -250,10 +257,16 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
                     if (NPL == 3) *reinterpret_cast<bf16x4*>(d + 2 * APLANE) = l;
                 }
             }
+            if constexpr (TERMS == 2) {
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
+                for (int jj = 0; jj < 4; ++jj)
+                    *reinterpret_cast<bf16x8*>(Bs + (wc8 >> 2) * BPLANE + (wr8 + 32 * jj) * SPLIT_RS + (wc8 & 3) * 8) = rw[jj >> 1][jj & 1];
+            } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(Bs + pl * BPLANE + (wr16 + 64 * j) * SPLIT_RS + wc16) = rw[pl][j];
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8*>(Bs + pl * BPLANE + (wr16 + 64 * j) * SPLIT_RS + wc16) = rw[pl][j];
+            }
         }
     };
 
@@ -577,13 +590,15 @@ void split_panel_host(const float* panel, size_t n, uint16_t* planes) {
     }
 }
 
-// TERMS = 2 planes: [h | l] fp16 with the scaled residual (same arithmetic as split_f16)
+// TERMS = 2 image: per row and 32-wide k group, 32 fp16 heads then the 32 scaled fp16 residuals (same arithmetic as
+// split_f16): a k-step's operand row is one whole 128-B line (half-line requests cost ~10 % in the lab, gemm_lab_planes.hip)
 __global__ void split_panel_f16_kernel(const float* __restrict__ panel, size_t n, _Float16* __restrict__ planes) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         _Float16 h, l;
         split_f16(panel[i], h, l);
-        planes[i] = h;
-        planes[n + i] = l;
+        const size_t o = (i >> 5) * 64 + (i & 31);      // Kp % 32 == 0: a group never straddles rows
+        planes[o] = h;
+        planes[o + 32] = l;
     }
 }
 hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hipStream_t s) {
@@ -600,8 +615,9 @@ void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes) {
         float r = (x - (float)h) * F16_RES_SCALE;
         r = r < -65504.f ? -65504.f : (r > 65504.f ? 65504.f : r);
         const _Float16 l = (_Float16)r;
-        memcpy(&planes[i], &h, 2);
-        memcpy(&planes[n + i], &l, 2);
+        const size_t o = (i >> 5) * 64 + (i & 31);
+        memcpy(&planes[o], &h, 2);
+        memcpy(&planes[o + 32], &l, 2);
     }
 }
 

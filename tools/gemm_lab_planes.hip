@@ -1,0 +1,227 @@
+// GEMM laboratory 3 (not part of the library): the fp16 two-term split GEMM with operands that are ALREADY split in memory
+// (two fp16 planes per operand, the low plane scaled by 2^11), so both tiles reach LDS by LDS-DMA (global_load_lds_dwordx4)
+// with no register staging and no split arithmetic in the loop.
+//   hipcc --offload-arch=gfx950 -O3 -w [-DNBUF=2] tools/gemm_lab_planes.hip -o tools/lab_planes.bin
+// C[M,N] = A[M,K] . W[N,K]^T
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#ifndef NBUF
+#define NBUF 2
+#endif
+#ifndef ILV
+#define ILV 0   // 1: operands stored [rows][K/32][h 32 | l 32] so every row piece is a full 128-B line
+#endif
+#ifndef MINB
+#define MINB 2
+#endif
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using h16 = _Float16;
+using h16x8 = __attribute__((ext_vector_type(8))) h16;
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PLANE_B = 128 * BK * 2;            // bytes of one plane of one operand tile (8 KiB), rows of 64 B, linear
+constexpr int STAGE_B = 4 * PLANE_B;             // Ah | Al | Wh | Wl
+constexpr int EPI_BYTES = 4 * 64 * 68 * 4;
+constexpr int LDS_BYTES = (NBUF * STAGE_B > EPI_BYTES) ? NBUF * STAGE_B : EPI_BYTES;
+
+__global__ void split_kernel(const float* __restrict__ x, h16* __restrict__ h, h16* __restrict__ l, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const h16 hh = (h16)fminf(fmaxf(v, -65504.f), 65504.f);
+        h[i] = hh;
+        l[i] = (h16)fminf(fmaxf((v - (float)hh) * 2048.0f, -65504.f), 65504.f);
+    }
+}
+__global__ void split_ilv_kernel(const float* __restrict__ x, h16* __restrict__ o, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const h16 hh = (h16)fminf(fmaxf(v, -65504.f), 65504.f);
+        const size_t g = i >> 5, e = i & 31;          // K % 32 == 0: groups never straddle rows
+        o[g * 64 + e] = hh;
+        o[g * 64 + 32 + e] = (h16)fminf(fmaxf((v - (float)hh) * 2048.0f, -65504.f), 65504.f);
+    }
+}
+
+#define GLDS16(gp, lp) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+__global__ __launch_bounds__(256, MINB) void gemm_planes(const h16* __restrict__ Ah, const h16* __restrict__ Al,
+                                                         const h16* __restrict__ Wh, const h16* __restrict__ Wl,
+                                                         float* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive ids of one XCD share the column panel
+    const int ntm = (M + BM - 1) / BM, ntn = N / BN, nwg = ntm * ntn;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tm = wg / ntn, tn = wg - tm * ntn;   // N-tiles of one M-tile run consecutively on one XCD (A panel stays in its L2)
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // DMA sources: a wave moves pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of every plane.  Lane i of a piece fills LDS
+    // bytes [16 i, 16 i + 16): row i>>2, slot i&3, which holds k-chunk (i&3) ^ ((row>>2)&3) (the read side applies the same
+    // involution: rule "swizzle both sides").
+#if ILV
+    // piece = 8 rows x 128 B (h|l of one 32-k group); a wave moves pieces 4*wave .. 4*wave+3 of A and of W
+    const h16* srcA[4]; const h16* srcW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j, rr = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+        srcA[j] = Ah + (size_t)min(row0 + rr, M - 1) * K * 2 + chunk * 8;
+        srcW[j] = Wh + (size_t)(col0 + rr) * K * 2 + chunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = lds + buf * STAGE_B + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            GLDS16(srcA[j] + kt * 64, base + j * 1024);
+            GLDS16(srcW[j] + kt * 64, base + 2 * PLANE_B + j * 1024);
+        }
+    };
+#else
+    const int prow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const h16* srcA[2]; const h16* srcW[2];
+    size_t dA, dW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = (wave * 2 + j) * 16 + prow;
+        srcA[j] = Ah + (size_t)min(row0 + rr, M - 1) * K + chunk * 8;
+        srcW[j] = Wh + (size_t)(col0 + rr) * K + chunk * 8;
+    }
+    dA = Al - Ah; dW = Wl - Wh;
+    auto issue = [&](int kt, int buf) {
+        char* base = lds + buf * STAGE_B + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            GLDS16(srcA[j] + kt * BK, base + 0 * PLANE_B + j * 1024);
+            GLDS16(srcA[j] + dA + kt * BK, base + 1 * PLANE_B + j * 1024);
+            GLDS16(srcW[j] + kt * BK, base + 2 * PLANE_B + j * 1024);
+            GLDS16(srcW[j] + dW + kt * BK, base + 3 * PLANE_B + j * 1024);
+        }
+    };
+#endif
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5, fswz = (fr >> 2) & 3;
+    const int nk = K / BK;
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = (NBUF == 2) ? (kt & 1) : 0;
+        if (NBUF == 2 && kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        const char* sb = lds + buf * STAGE_B;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            h16x8 ah[2], al[2], bh[2], bl[2];
+#if ILV
+            const int f8 = (fr >> 1) & 7;
+            const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ro = (wm * 64 + i * 32 + fr) * 128;
+                ah[i] = *reinterpret_cast<const h16x8*>(sb + ro + sh);
+                al[i] = *reinterpret_cast<const h16x8*>(sb + ro + sl);
+                const int co = 2 * PLANE_B + (wn * 64 + i * 32 + fr) * 128;
+                bh[i] = *reinterpret_cast<const h16x8*>(sb + co + sh);
+                bl[i] = *reinterpret_cast<const h16x8*>(sb + co + sl);
+            }
+#else
+            const int slot = ((2 * kb + fh) ^ fswz) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ro = (wm * 64 + i * 32 + fr) * 64 + slot;
+                ah[i] = *reinterpret_cast<const h16x8*>(sb + 0 * PLANE_B + ro);
+                al[i] = *reinterpret_cast<const h16x8*>(sb + 1 * PLANE_B + ro);
+                const int co = (wn * 64 + i * 32 + fr) * 64 + slot;
+                bh[i] = *reinterpret_cast<const h16x8*>(sb + 2 * PLANE_B + co);
+                bl[i] = *reinterpret_cast<const h16x8*>(sb + 3 * PLANE_B + co);
+            }
+#endif
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (NBUF == 1 && kt + 1 < nk) { issue(kt + 1, 0); __syncthreads(); }
+    }
+    // epilogue: park the wave tile in LDS, write float4 rows
+    float* et = reinterpret_cast<float*>(lds) + wave * 64 * 68;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, cc = j * 32 + fr;
+                et[rr * 68 + cc] = acc[i][j][e] + accx[i][j][e] * (1.0f / 2048.0f);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        const int grow = row0 + wm * 64 + rr;
+        if (grow < M) *reinterpret_cast<f32x4*>(C + (size_t)grow * N + col0 + wn * 64 + cc) = *reinterpret_cast<const f32x4*>(et + rr * 68 + cc);
+    }
+}
+
+int main(int argc, char** argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 20480, N = argc > 2 ? atoi(argv[2]) : 1152, K = argc > 3 ? atoi(argv[3]) : 384;
+    int iters = argc > 4 ? atoi(argv[4]) : 50;
+    std::vector<float> hA((size_t)M * K), hW((size_t)N * K);
+    uint64_t s = 12345;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((int64_t)(s >> 11) % 200001 - 100000) * 1e-5f; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hW) v = rnd() * 0.1f;
+    float *dA, *dW, *dC; h16 *pA, *pW;
+    hipMalloc(&dA, hA.size() * 4); hipMalloc(&dW, hW.size() * 4); hipMalloc(&dC, (size_t)M * N * 4);
+    hipMalloc(&pA, hA.size() * 4); hipMalloc(&pW, hW.size() * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
+#if ILV
+    split_ilv_kernel<<<1024, 256>>>(dA, pA, hA.size());
+    split_ilv_kernel<<<1024, 256>>>(dW, pW, hW.size());
+#else
+    split_kernel<<<1024, 256>>>(dA, pA, pA + hA.size(), hA.size());
+    split_kernel<<<1024, 256>>>(dW, pW, pW + hW.size(), hW.size());
+#endif
+    const int grid = ((M + BM - 1) / BM) * (N / BN);
+    hipFuncSetAttribute((const void*)gemm_planes, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    auto run = [&]() { gemm_planes<<<grid, 256, LDS_BYTES>>>(pA, pA + hA.size(), pW, pW + hW.size(), dC, M, N, K); };
+    run();
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+    std::vector<float> hC((size_t)M * N);
+    hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0, maxref = 0;
+    for (int t = 0; t < 4000; ++t) {
+        const int i = (int)((t * 7919ull) % M), j = (int)((t * 104729ull) % N);
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)i * K + k] * hW[(size_t)j * K + k];
+        maxerr = std::max(maxerr, std::fabs(ref - hC[(size_t)i * N + j]));
+        maxref = std::max(maxref, std::fabs(ref));
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) run();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) run();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("planes ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", ILV, NBUF, MINB, M, N, K, grid,
+           LDS_BYTES, us, tf, maxerr, maxref);
+    return 0;
+}
