@@ -142,6 +142,19 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
                   const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc,
                   float* d_stats_out, int terms, void* stream);
 
+/* P16 GEMM (csrc/gemm_p16.hip): same contract as mtts_gemm_f32 in its fp16-split mode, but the A operand is first
+ * written as a "P16" image (fp16 head + scaled fp16 residual, 128-B lines per 32 channels; here by a conversion pass into
+ * d_scratch, in the model by the producing kernel's epilogue) and both tiles reach LDS by LDS-DMA.  C % 32 == 0, N % 4 == 0.
+ * LayerNorm statistics (arrays or partial moments) are applied in the epilogue: rstd * (x.W - mean * rowsum(W)).
+ * d_out (fp32) and/or d_out16_f32 (the P16 output image decoded back to fp32 [M][N], N % 32 == 0, residual scale
+ * out_lscale) receive the result.  Replaces F.linear / F.conv1d like mtts_gemm_f32 (reference decoder.py, transformer.py). */
+int64_t mtts_gemm_p16_scratch_bytes(int B, int T_in, int C, int T_out, int N);
+int mtts_gemm_p16(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride, int T_out,
+                  const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_a_part, int a_nparts,
+                  const float* d_w, void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
+                  const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc,
+                  float* d_out16_f32, float out_lscale, float* d_stats_out, int force_bm, void* d_scratch, void* stream);
+
 /* Self-attention over packed [B*T, 3*H*D] q|k|v rows -> [B*T, H*D].  mask_mode 0: additive float key bias
  * (diffusers semantics, reference transformer.py:253-258); 1: boolean query*key mask (reference
  * text_encoder.py:228-235,306).  d_mask [B,T] float 0/1. */

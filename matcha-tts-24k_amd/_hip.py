@@ -19,8 +19,8 @@ from .hparams import PathHParams
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmtts_hip.so"
-SOURCES = ["gemm_f32.hip", "attention_f32.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
-HEADERS = [CSRC / "kernels.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
+SOURCES = ["gemm_f32.hip", "attention_f32.hip", "gemm_p16.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
+HEADERS = [CSRC / "kernels.h", CSRC / "device_utils.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
 SOLVERS = {"euler": 0, "midpoint": 1, "rk4": 2}
 
 
@@ -85,6 +85,9 @@ def load() -> C.CDLL:
         "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
         "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
+        "mtts_gemm_p16_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
+        "mtts_gemm_p16": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
+                                i32, vp, f32, vp, i32, vp, f32, vp, i32, vp, vp]),
         "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
                                 i32, vp, f32, vp, i32, vp, i32, vp]),
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
@@ -335,6 +338,28 @@ def gemm_f32(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1,
                             res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N, ptr(stats), terms,
                             stream_ptr()))
     return (out, stats) if stats_out else out
+
+
+def gemm_p16(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1, a_mask=None, a_mean=None, a_rstd=None,
+             a_part=None, act=0, p0=None, p1=None, res=None, out_mask=None, out_scale=1.0, stats_out=False, want_f32=True,
+             want_p16=False, lscale=2048.0, force_bm=0):
+    """P16-operand GEMM (csrc/gemm_p16.hip); a [B*T_in, C] fp32 is converted to its P16 image first.  Returns a dict."""
+    lib = load()
+    N, Cc = w.shape[0], w.shape[1]
+    ntaps = w.shape[2] if w.dim() == 3 else 1
+    T_out = T_in if T_out is None else T_out
+    taps = (C.c_int * ntaps)(*(tap_off if tap_off is not None else [j - ntaps // 2 for j in range(ntaps)]))
+    packed = torch.empty(lib.mtts_gemm_packed_bytes(N, Cc, ntaps), dtype=torch.uint8, device=a.device)
+    scratch = torch.empty(lib.mtts_gemm_p16_scratch_bytes(B, T_in, Cc, T_out, N), dtype=torch.uint8, device=a.device)
+    out = torch.empty(B * T_out, N, dtype=torch.float32, device=a.device) if want_f32 else None
+    out16 = torch.empty(B * T_out, N, dtype=torch.float32, device=a.device) if want_p16 else None
+    stats = torch.empty(B * T_out, N // 64, 2, dtype=torch.float32, device=a.device) if stats_out else None
+    check(lib.mtts_gemm_p16(ptr(a), a.shape[1], B, T_in, Cc, ntaps, taps, in_stride, T_out, ptr(a_mask), ptr(a_mean), ptr(a_rstd),
+                            ptr(a_part), a_part.shape[1] if a_part is not None else 0,
+                            ptr(w.contiguous()), packed.data_ptr(), ptr(bias), N, act, ptr(p0), ptr(p1), ptr(res),
+                            res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N,
+                            ptr(out16), float(lscale), ptr(stats), force_bm, scratch.data_ptr(), stream_ptr()))
+    return {"out": out, "out16": out16, "stats": stats}
 
 
 def attention_f32(qkv, mask, B, T, H, D, scale, mask_mode):

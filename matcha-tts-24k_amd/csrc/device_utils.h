@@ -1,0 +1,66 @@
+// Device helpers shared by the GEMM kernels (gemm_f32.hip, gemm_p16.hip), attention and the normalisation kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace mtts {
+
+constexpr float F16_RES_SCALE = 2048.0f;   // fp16 two-term split: the residual is stored times 2^11
+
+// x ~ h + l / 2^11 with h = fp16(x) (saturating) and l the scaled fp16 residual: 22 significand bits
+__device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
+    const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
+    h = (_Float16)xc;
+    l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
+}
+
+// sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 and the two minimax kernels on
+// [-pi/4, pi/4]; the quadrant only selects which kernel is squared, so no sign handling.  ~1 ulp of sinf for |y| < 1e4
+// (arguments here are O(10)), about a third of the instructions of the library sinf.
+__device__ __forceinline__ float sin_sq(float y) {
+    const float n = rintf(y * 0.63661977236758134308f);
+    float r = fmaf(n, -1.5707962513e+00f, y);       // pi/2 split: hi, mid, lo
+    r = fmaf(n, -7.5497894159e-08f, r);
+    r = fmaf(n, -5.3903029534e-15f, r);
+    const float z = r * r;
+    // sin(r) = r + r*z*(S1 + z*(S2 + z*(S3 + z*S4)));  cos(r) = 1 - z/2 + z*z*(C1 + z*(C2 + z*C3))
+    const float sp = fmaf(z, fmaf(z, fmaf(z, 2.7183114939e-06f, -1.9839334836e-04f), 8.3333298564e-03f), -1.6666665459e-01f);
+    const float sn = fmaf(r * z, sp, r);
+    const float cp = fmaf(z, fmaf(z, -1.3887316255e-03f, 4.1666645683e-02f) + z * z * 2.4390448928e-05f, -0.5f);
+    const float cs = fmaf(z, cp, 1.0f);
+    const float v = (((int)n) & 1) ? cs : sn;
+    return v * v;
+}
+
+__device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
+    switch (act) {
+        case ACT_RELU: return c > 0.f ? c : 0.f;
+        case ACT_SILU: return c / (1.0f + expf(-c));
+        case ACT_SNAKE: {   // reference transformer.py:75: x + 1/(beta+1e-9) * sin(x*alpha)^2
+            return c + p1 * sin_sq(c * p0);
+        }
+        case ACT_GELU: return 0.5f * c * (1.0f + erff(c * 0.70710678118654752440f));   // exact GELU (vocos ConvNeXtBlock)
+        default: return c;
+    }
+}
+
+
+// DPP all-reduce sums (every lane gets the total): 16-lane rows via row_mirror, row_half_mirror, quad reverse, quad swap;
+// 8-lane groups skip the first step.  One VALU instruction per step instead of a ds_bpermute round trip.
+#define MTTS_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ float allreduce16(float v) {
+    v = MTTS_DPP_ADD(v, 0x140);   // row_mirror
+    v = MTTS_DPP_ADD(v, 0x141);   // row_half_mirror
+    v = MTTS_DPP_ADD(v, 0x1B);    // quad_perm [3,2,1,0]
+    v = MTTS_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
+    return v;
+}
+__device__ __forceinline__ float allreduce8(float v) {
+    v = MTTS_DPP_ADD(v, 0x141);
+    v = MTTS_DPP_ADD(v, 0x1B);
+    v = MTTS_DPP_ADD(v, 0xB1);
+    return v;
+}
+
+
+}  // namespace mtts

@@ -30,6 +30,7 @@
 //      block (3/16 of the fp32-MFMA cycles).  Measured error vs fp64 equals the fp32 chain's.  Inputs beyond the fp16
 //      range (|x| > 65504) saturate instead of overflowing.
 #include "kernels.h"
+#include "device_utils.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -51,18 +52,12 @@ constexpr int tile_floats(int BM) { return (BM + GEMM_BN) * LDS_STRIDE; }
 // (4 waves x BM/2 rows x 68 floats) reuses the same LDS and is the larger of the two at BM = 128.
 constexpr int SPLIT_RS = 40;                                         // row stride in bf16 elements
 constexpr int split_planes(int terms) { return terms == 6 ? 3 : 2; }
-constexpr float F16_RES_SCALE = 2048.0f;                              // TERMS = 2: residual stored times 2^11
 constexpr int epi_bytes(int BM) { return 4 * (BM / 2) * 68 * 4; }
 constexpr int gemm_lds_bytes(int BM, int terms) {
     const int stage = terms == 0 ? 2 * tile_floats(BM) * 4 : split_planes(terms) * (BM + GEMM_BN) * SPLIT_RS * 2;
     return stage > epi_bytes(BM) ? stage : epi_bytes(BM);
 }
 
-__device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
-    const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
-    h = (_Float16)xc;
-    l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
-}
 // x = h + m + l exactly (three round-to-nearest bf16 terms of 8 significand bits each; the subtractions are exact)
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -71,55 +66,8 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
-// sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 and the two minimax kernels on
-// [-pi/4, pi/4]; the quadrant only selects which kernel is squared, so no sign handling.  ~1 ulp of sinf for |y| < 1e4
-// (arguments here are O(10)), about a third of the instructions of the library sinf.
-__device__ __forceinline__ float sin_sq(float y) {
-    const float n = rintf(y * 0.63661977236758134308f);
-    float r = fmaf(n, -1.5707962513e+00f, y);       // pi/2 split: hi, mid, lo
-    r = fmaf(n, -7.5497894159e-08f, r);
-    r = fmaf(n, -5.3903029534e-15f, r);
-    const float z = r * r;
-    // sin(r) = r + r*z*(S1 + z*(S2 + z*(S3 + z*S4)));  cos(r) = 1 - z/2 + z*z*(C1 + z*(C2 + z*C3))
-    const float sp = fmaf(z, fmaf(z, fmaf(z, 2.7183114939e-06f, -1.9839334836e-04f), 8.3333298564e-03f), -1.6666665459e-01f);
-    const float sn = fmaf(r * z, sp, r);
-    const float cp = fmaf(z, fmaf(z, -1.3887316255e-03f, 4.1666645683e-02f) + z * z * 2.4390448928e-05f, -0.5f);
-    const float cs = fmaf(z, cp, 1.0f);
-    const float v = (((int)n) & 1) ? cs : sn;
-    return v * v;
-}
-
-__device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
-    switch (act) {
-        case ACT_RELU: return c > 0.f ? c : 0.f;
-        case ACT_SILU: return c / (1.0f + expf(-c));
-        case ACT_SNAKE: {   // reference transformer.py:75: x + 1/(beta+1e-9) * sin(x*alpha)^2
-            return c + p1 * sin_sq(c * p0);
-        }
-        case ACT_GELU: return 0.5f * c * (1.0f + erff(c * 0.70710678118654752440f));   // exact GELU (vocos ConvNeXtBlock)
-        default: return c;
-    }
-}
-
 // BM = 128: wave tile 64x64 (2x2 MFMA tiles).  BM = 64: wave tile 32x64 (1x2), used when the 128-row grid would leave
 // CUs with a single resident workgroup (nothing to overlap its staging with).
-// DPP all-reduce sums (every lane gets the total): 16-lane rows via row_mirror, row_half_mirror, quad reverse, quad swap;
-// 8-lane groups skip the first step.  One VALU instruction per step instead of a ds_bpermute round trip.
-#define MTTS_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
-__device__ __forceinline__ float allreduce16(float v) {
-    v = MTTS_DPP_ADD(v, 0x140);   // row_mirror
-    v = MTTS_DPP_ADD(v, 0x141);   // row_half_mirror
-    v = MTTS_DPP_ADD(v, 0x1B);    // quad_perm [3,2,1,0]
-    v = MTTS_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
-    return v;
-}
-__device__ __forceinline__ float allreduce8(float v) {
-    v = MTTS_DPP_ADD(v, 0x141);
-    v = MTTS_DPP_ADD(v, 0x1B);
-    v = MTTS_DPP_ADD(v, 0xB1);
-    return v;
-}
-
 __device__ __forceinline__ int round_up_dev(int n) { return (n + GEMM_BN - 1) / GEMM_BN * GEMM_BN; }
 
 // Registers: the 64-row split-mode tile is held to 168 VGPRs (3 waves per SIMD = 3 workgroups per CU; its LDS footprint
@@ -514,6 +462,7 @@ static hipError_t launch_terms(const GemmArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.a16_0) return launch_gemm_p16(a, s);     // operands already split in memory: gemm_p16.hip
     // shape contract (the kernel indexes without further checks)
     if (!a.a0 || (!a.w && !a.w16) || !a.out || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
     if (a.ntaps < 1 || a.ntaps > MAX_TAPS) return hipErrorInvalidValue;

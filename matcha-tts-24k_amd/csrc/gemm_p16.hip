@@ -1,0 +1,338 @@
+// GEMM / implicit conv1d on operands that are ALREADY fp16-split in memory ("P16" images, kernels.h) for gfx950.
+//
+// Same arithmetic as gemm_f32.hip's TERMS = 2 mode (x = h + l / 2^11, products h.h + (h.l + l.h) / 2^11 accumulated in fp32
+// by three v_mfma_f32_32x32x16_f16 per 16-deep block, two accumulators), but the producer of the activations has done the
+// split once, in its epilogue, so this kernel's loop has no split arithmetic, no staging registers and no LDS stores: both
+// tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per k-step.
+//
+//   LDS image of a tile: rows of 128 B = [32 heads | 32 residuals] of one 32-wide k group, lane-linear per DMA piece
+//   (a piece = one wave instruction = 8 rows x 128 B).  16-B chunk c of row r lives in slot c ^ ((r >> 1) & 7): the
+//   involution is applied to the per-lane SOURCE address of the DMA and again by the fragment reads, which makes the
+//   32-row x 16-B fragment reads conflict-free.
+//   Every operand row of a k-step is one whole 128-B line: half-line requests measured ~10 % slower (tools/gemm_lab_planes.hip).
+//
+// What the loop cannot do any more moves to the epilogue: LayerNorm of the A rows is applied as
+//   LN(x) . W'^T = rstd * (x . W'^T - mean * wsum),   wsum[n] = sum_k W'[n][k]
+// (exact algebra; the row moments come from the producer's 64-column partials or from arrays), and row masks are the
+// producer's job (P16 images are written already masked).
+// Replaces, like gemm_f32.hip: nn.Linear / nn.Conv1d of the reference decoder (decoder.py, transformer.py) on the hot path.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace mtts {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+__device__ __attribute__((aligned(128))) _Float16 g_p16_zero_line[64];     // source of out-of-range conv taps (zero-initialised)
+
+constexpr int P16_CS = 68;                                                  // epilogue tile row stride (floats)
+constexpr int p16_stage_bytes(int BM) { return (BM + GEMM_BN) * 128; }
+constexpr int p16_epi_bytes(int BM) { return 4 * (BM / 2) * P16_CS * 4; }
+constexpr int p16_main_bytes(int BM) { return 2 * p16_stage_bytes(BM) > p16_epi_bytes(BM) ? 2 * p16_stage_bytes(BM) : p16_epi_bytes(BM); }
+constexpr int p16_lds_bytes(int BM) { return p16_main_bytes(BM) + 2 * BM * 4; }   // + per-row (mean, rstd)
+
+#define MTTS_GLDS16(gp, lp) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+template <int BM, bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
+    constexpr int MI = BM / 64;            // 32-row MFMA tiles per wave along M
+    constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
+    constexpr int STAGE = p16_stage_bytes(BM);
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE array: stages | epilogue tile | row statistics
+    float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.B * p.T_out;
+    const int Kp = p.ntaps * p.ktap;
+    const int n_tiles = (p.N + GEMM_BN - 1) / GEMM_BN;
+    int swz;   // XCD-aware order: the N-tiles of one M-tile run consecutively on one XCD (same remap as gemm_f32.hip)
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int m0 = (swz / n_tiles) * BM;
+    const int n0 = (swz % n_tiles) * GEMM_BN;
+
+    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue
+    if (LN) {
+        if (tid < BM) {
+            const int row = min(m0 + tid, M - 1);
+            float mean, rstd;
+            if (p.a_part) {
+                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
+                float sm = 0.f, m2 = 0.f;
+                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                mean = sm / (float)p.a_nparts;
+                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
+            } else {
+                mean = p.a_mean[row];
+                rstd = p.a_rstd[row];
+            }
+            srow[tid] = mean;
+            srow[BM + tid] = rstd;
+        }
+    }
+
+    // ---- DMA coordinates.  Piece pa of the A tile = rows 8 pa .. 8 pa + 7; lane i fills LDS bytes [16 i, 16 i + 16) of the
+    // piece = row i>>3, slot i&7, which must hold chunk (i&7) ^ ((row>>1)&7), row>>1 = 4 pa + (i>>4).
+    int a_base[APW], a_t[APW], a_chunk[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int pa = wave * APW + j;
+        const int m = m0 + pa * 8 + (lane >> 3);
+        a_chunk[j] = ((lane & 7) ^ (((pa & 1) * 4 + (lane >> 4)) & 7)) * 8;
+        if (m < M) {
+            const int b = m / p.T_out;
+            a_base[j] = b * p.T_in;
+            a_t[j] = (m - b * p.T_out) * p.in_stride;
+        } else {
+            a_base[j] = 0;
+            a_t[j] = -(1 << 28);
+        }
+    }
+    const _Float16* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pw = wave * 4 + j;
+        const int chunk = (lane & 7) ^ (((pw & 1) * 4 + (lane >> 4)) & 7);
+        wsrc[j] = reinterpret_cast<const _Float16*>(p.w16) + (size_t)(n0 + pw * 8 + (lane >> 3)) * Kp * 2 + chunk * 8;
+    }
+    int ld_tap = 0, ld_c = 0, ld_k = 0;    // (tap, channel, k-step) of the next tile to request
+    auto issue = [&](int buf) {
+        char* st = lds + buf * STAGE;
+        const bool seg1 = p.a16_1 != nullptr && ld_c >= p.c0;           // wave-uniform
+        const _Float16* src = seg1 ? p.a16_1 : p.a16_0;
+        const int ld = seg1 ? p.lda16_1 : p.lda16_0;
+        const int goff = ((seg1 ? ld_c - p.c0 : ld_c) >> 5) * 64;
+        const int off = p.tap_off[ld_tap];
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int tin = a_t[j] + off;
+            const bool ok = (unsigned)tin < (unsigned)p.T_in;
+            const _Float16* gp = ok ? src + (size_t)(a_base[j] + tin) * ld + goff + a_chunk[j] : g_p16_zero_line + a_chunk[j];
+            MTTS_GLDS16(gp, st + (wave * APW + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) MTTS_GLDS16(wsrc[j] + (size_t)ld_k * 64, st + BM * 128 + (wave * 4 + j) * 1024);
+        ld_c += GEMM_BK;
+        ++ld_k;
+        if (ld_c >= p.ktap) { ld_c = 0; ++ld_tap; }
+    };
+
+    f32x16 acc[MI][2], accx[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    // fragment of v_mfma_f32_32x32x16_f16: lane (r = lane&31, h = lane>>5) holds k = 8h .. 8h+7 of a 16-wide k block
+    const int fr = lane & 31, fh = lane >> 5, f8 = (fr >> 1) & 7;
+    const int nk = Kp / GEMM_BK;
+    issue(0);
+    __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue(buf ^ 1);   // the other buffer was last read before the barrier that ended step kt-1
+        const char* sa = lds + buf * STAGE + (wm * (BM / 2) + fr) * 128;
+        const char* sw = lds + buf * STAGE + BM * 128 + (wn * 64 + fr) * 128;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
+            f16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sh);
+                al[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sl);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sh);
+                bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sl);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                   // tile kt+1 landed (vmcnt(0)) and everyone is done reading tile kt
+    }
+
+    // ---- epilogue: park the wave's tile in LDS, re-read it as rows of float4 (16 lanes per row)
+    float* Cw = reinterpret_cast<float*>(lds) + wave * ((BM / 2) * P16_CS);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * P16_CS + j * 32 + fr] = acc[i][j][r] + accx[i][j][r] * (1.0f / F16_RES_SCALE);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
+    __builtin_amdgcn_wave_barrier();
+
+    const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+    const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns (N % 4 == 0 is required)
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, ws4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nc < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p.bias) bias4[e] = p.bias[nc + e];
+            if (p.act == ACT_SNAKE) { s0[e] = p.p0[nc + e]; s1[e] = p.p1[nc + e]; }
+            if (LN) ws4[e] = p.wsum[nc + e];
+        }
+    }
+    for (int it = 0; it < BM / 8; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int m = m0 + wm * (BM / 2) + rl;
+        if (m >= M || nc >= p.N) continue;
+        int orow = m;
+        if (!plain_rows) {
+            const int b = m / p.T_out;
+            orow = b * p.out_T + (m - b * p.T_out) * p.out_stride + p.out_off;
+        }
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * P16_CS + (lane & 15) * 4);
+        float mean = 0.f, rstd = 1.f;
+        if (LN) { mean = srow[wm * (BM / 2) + rl]; rstd = srow[BM + wm * (BM / 2) + rl]; }
+        const float om = p.out_mask ? p.out_mask[orow] : 1.0f;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = a[e];
+            if (LN) v = rstd * (v - mean * ws4[e]);
+            v = act_apply(v + bias4[e], p.act, s0[e], s1[e]);
+            if (p.out_mask) v *= om;
+            if (p.out_scale != 1.0f) v *= p.out_scale;
+            o[e] = v;
+        }
+        if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)orow * p.ldr + nc);
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)orow * p.ldc + nc) = o;
+        if (p.out16) {                     // P16 copy for the next GEMM / attention: 8 lanes write one whole 128-B line
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xc = fminf(fmaxf(o[e], -65504.f), 65504.f);
+                h[e] = (_Float16)xc;
+                l[e] = (_Float16)fminf(fmaxf((o[e] - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
+            }
+            _Float16* o16 = p.out16 + (size_t)orow * p.ld16 + (nc >> 5) * 64 + (nc & 31);
+            *reinterpret_cast<f16x4*>(o16) = h;
+            *reinterpret_cast<f16x4*>(o16 + 32) = l;
+        }
+        if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 16 lanes lane&15 hold them
+            const float mu = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
+            const f32x4 d = o - mu;
+            const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+            if ((lane & 15) == 0) {
+                float* so = p.stats_out + ((size_t)orow * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                so[0] = mu;
+                so[1] = m2;
+            }
+        }
+    }
+}
+
+template <int BM, bool LN>
+static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
+    static bool configured = false;   // per instantiation
+    auto kern = gemm_p16_kernel<BM, LN>;
+    constexpr int lds_bytes = p16_lds_bytes(BM);
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int M = a.B * a.T_out;
+    const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
+    // shape contract (the kernel indexes without further checks)
+    if (!a.a16_0 || !a.w16 || a.terms != 2 || (!a.out && !a.out16) || a.N <= 0 || (a.N & 3) || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0)
+        return hipErrorInvalidValue;
+    if (a.ntaps < 1 || a.ntaps > MAX_TAPS || a.ktap <= 0 || a.ktap % GEMM_BK != 0) return hipErrorInvalidValue;
+    if ((a.c0 % GEMM_BK) || (a.c1 % GEMM_BK) || a.c0 + a.c1 != a.ktap) return hipErrorInvalidValue;   // images are physically padded
+    if ((a.a16_1 == nullptr) != (a.c1 == 0)) return hipErrorInvalidValue;
+    if (a.lda16_0 < 2 * a.c0 || (a.lda16_0 & 7) || (a.a16_1 && (a.lda16_1 < 2 * a.c1 || (a.lda16_1 & 7)))) return hipErrorInvalidValue;
+    if (a.a_mask) return hipErrorInvalidValue;                       // P16 images are written already masked
+    if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
+    if (a.a_part && (a.a_mean || a.a_nparts <= 0)) return hipErrorInvalidValue;
+    const bool ln = a.a_mean || a.a_part;
+    if (ln && (!a.wsum || a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0 || a.T_in != a.T_out)) return hipErrorInvalidValue;
+    if (a.out && (a.ldc & 3)) return hipErrorInvalidValue;
+    if (a.res && (a.ldr & 3)) return hipErrorInvalidValue;
+    if (a.out16 && ((a.N % 32) || a.ld16 < 2 * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
+    if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
+    if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
+    // Block-tile height by grid fill, as launch_gemm: 2 resident workgroups per CU for either height (LDS 70 / 49 KB).
+    const int M = a.B * a.T_out;
+    const int nt = (a.N + GEMM_BN - 1) / GEMM_BN;
+    auto fill = [&](int bm) {
+        const int tiles = ((M + bm - 1) / bm) * nt;
+        const int rounds = (tiles + 511) / 512;
+        return (double)tiles / (rounds * 512.0) * ((double)M / (((M + bm - 1) / bm) * bm));
+    };
+    const bool bm64 = a.force_bm == 64 || (a.force_bm == 0 && 0.97 * fill(64) > fill(128));
+    if (bm64) return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
+    return ln ? launch_p16_variant<128, true>(a, s) : launch_p16_variant<128, false>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 <-> P16
+__global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C,
+                              _Float16* __restrict__ out, int ld16, float lscale) {
+    const int c4n = C >> 2;
+    const size_t n = (size_t)M * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c4n), c = (int)(i - (size_t)row * c4n) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + c);
+        if (mask) v *= mask[row];
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
+            l[e] = (_Float16)fminf(fmaxf((v[e] - (float)h[e]) * lscale, -65504.f), 65504.f);
+        }
+        _Float16* o = out + (size_t)row * ld16 + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<f16x4*>(o) = h;
+        *reinterpret_cast<f16x4*>(o + 32) = l;
+    }
+}
+hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, _Float16* out, int ld16, float lscale, hipStream_t s) {
+    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || ld < C || ld16 < 2 * C || (ld16 & 3)) return hipErrorInvalidValue;
+    const size_t n = (size_t)M * (C >> 2);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, out, ld16, lscale);
+    return hipGetLastError();
+}
+__global__ void from_p16_kernel(const _Float16* __restrict__ x, int ld16, int M, int C, float inv_lscale, float* __restrict__ out, int ld) {
+    const size_t n = (size_t)M * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
+        const _Float16* q = x + (size_t)row * ld16 + (c >> 5) * 64 + (c & 31);
+        out[(size_t)row * ld + c] = (float)q[0] + (float)q[32] * inv_lscale;
+    }
+}
+hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s) {
+    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || ld < C || ld16 < 2 * C || lscale == 0.f) return hipErrorInvalidValue;
+    const size_t n = (size_t)M * C;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(from_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld16, M, C, 1.0f / lscale, out, ld);
+    return hipGetLastError();
+}
+
+}  // namespace mtts

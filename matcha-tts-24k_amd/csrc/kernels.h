@@ -52,8 +52,24 @@ struct GemmArgs {
     float* stats_out = nullptr;       // [M][N/64][2]: (mean, M2) of every 64-column slice of the output rows (N % 64 == 0)
     int out_T = 1, out_stride = 1, out_off = 0;   // output row = b*out_T + t*out_stride + out_off
     int force_bm = 0;                 // 0 = choose the block tile height from the grid size; 64 / 128 = force (tests)
+    // ---- P16 operands (gemm_p16.hip; terms == 2 only).  A "P16" tensor is the fp16 two-term split of an fp32 tensor kept
+    // in memory: row-major, per row and 32-channel group 32 heads then 32 residuals (64 halves = one 128-B line), so a
+    // tensor of C channels has rows of 2*C halves.  When a16_0 is set the A tiles come from these images by LDS-DMA and
+    // a0/a1/a_mask are ignored; LayerNorm (a_part or a_mean/a_rstd) is then applied in the epilogue as
+    // rstd * (x.W' - mean * wsum) with wsum[n] = sum_k W'[n][k].
+    const _Float16* a16_0 = nullptr;  // segment 0 image, c0 % 32 == 0
+    const _Float16* a16_1 = nullptr;  // segment 1 image or null, c1 % 32 == 0
+    int lda16_0 = 0, lda16_1 = 0;     // row strides in halves
+    const float* wsum = nullptr;      // [Np] row sums of the panel (LayerNorm-in-the-epilogue)
+    _Float16* out16 = nullptr;        // optional P16 copy of the output (N % 32 == 0)
+    int ld16 = 0;                     // its row stride in halves
+    float out_lscale = 2048.0f;       // residual scale of out16: 2048 for GEMM operands, 1 for the attention kernel's q|k|v
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
+// fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
+hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, _Float16* out, int ld16, float lscale, hipStream_t s);
+hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
 }

@@ -959,6 +959,57 @@ int mtts_gemm_f32(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
     return 0;
 }
 
+// Test entry for the P16 GEMM (gemm_p16.hip): the fp32 operand is converted to its P16 image (optionally masked) in
+// d_scratch, the panel is packed as for mtts_gemm_f32 (terms = 2) and its row sums are computed for the LayerNorm algebra;
+// the optional P16 output is decoded back to fp32 into d_out16_f32.
+int64_t mtts_gemm_p16_scratch_bytes(int B, int T_in, int C, int T_out, int N) {
+    return (int64_t)B * T_in * C * 4 + (int64_t)B * T_out * round_up(N, 32) * 4 + (int64_t)round_up(N, GEMM_BN) * 4 + 1024;
+}
+__global__ void panel_rowsum_kernel(const float* __restrict__ panel, int Np, int Kp, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    double acc = 0.0;
+    for (int k = 0; k < Kp; ++k) acc += (double)panel[(size_t)n * Kp + k];
+    out[n] = (float)acc;
+}
+int mtts_gemm_p16(const float* d_a, int lda, int B, int T_in, int C, int ntaps, const int* h_tap_off, int in_stride, int T_out,
+                  const float* d_a_mask, const float* d_a_mean, const float* d_a_rstd, const float* d_a_part, int a_nparts,
+                  const float* d_w, void* d_wpacked, const float* d_bias, int N, int act, const float* d_p0, const float* d_p1,
+                  const float* d_res, int ldr, const float* d_out_mask, float out_scale, float* d_out, int ldc,
+                  float* d_out16_f32, float out_lscale, float* d_stats_out, int force_bm, void* d_scratch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ntaps < 1 || ntaps > MAX_TAPS) { set_error("ntaps out of range"); return -1; }
+    if (C % GEMM_BK) { set_error("P16 operands need C % 32 == 0"); return -1; }
+    if (!d_w || !d_wpacked || !d_scratch) { set_error("null buffer"); return -1; }
+    const int Np = round_up(N, GEMM_BN), Kp = ntaps * C;
+    const size_t npanel = (size_t)Np * Kp;
+    float* planes = static_cast<float*>(d_wpacked) + ((npanel + 63) & ~size_t(63));
+    HIP_OK(launch_pack_weight(d_w, N, C, ntaps, static_cast<float*>(d_wpacked), s));
+    HIP_OK(launch_split_panel_f16(static_cast<const float*>(d_wpacked), npanel, planes, s));
+    char* sc = static_cast<char*>(d_scratch);
+    _Float16* a16 = reinterpret_cast<_Float16*>(sc);
+    sc += (size_t)B * T_in * C * 4;
+    _Float16* o16 = reinterpret_cast<_Float16*>(sc);
+    sc += (size_t)B * T_out * round_up(N, 32) * 4;
+    float* wsum = reinterpret_cast<float*>(sc);
+    HIP_OK(launch_to_p16(d_a, lda, d_a_mask, B * T_in, C, a16, 2 * C, 2048.0f, s));
+    hipLaunchKernelGGL(panel_rowsum_kernel, dim3((Np + 127) / 128), dim3(128), 0, s, static_cast<const float*>(d_wpacked), Np, Kp, wsum);
+    HIP_OK(hipGetLastError());
+    GemmArgs a;
+    a.a16_0 = a16; a.lda16_0 = 2 * C; a.c0 = C; a.ktap = C; a.ntaps = ntaps;
+    for (int j = 0; j < ntaps; ++j) a.tap_off[j] = h_tap_off ? h_tap_off[j] : 0;
+    a.in_stride = in_stride; a.B = B; a.T_in = T_in; a.T_out = T_out;
+    a.a_mean = d_a_mean; a.a_rstd = d_a_rstd; a.a_part = d_a_part; a.a_nparts = a_nparts; a.wsum = wsum;
+    a.stats_out = d_stats_out;
+    a.w16 = planes; a.terms = 2; a.bias = d_bias; a.N = N; a.act = act; a.p0 = d_p0; a.p1 = d_p1;
+    a.res = d_res; a.ldr = ldr; a.out_mask = d_out_mask; a.out_scale = out_scale; a.out = d_out; a.ldc = ldc;
+    if (d_out16_f32) { a.out16 = o16; a.ld16 = 2 * N; a.out_lscale = out_lscale; }
+    a.out_T = T_out; a.out_stride = 1; a.out_off = 0; a.force_bm = force_bm;
+    HIP_OK(launch_gemm(a, s));
+    if (d_out16_f32) HIP_OK(launch_from_p16(o16, 2 * N, B * T_out, N, out_lscale, d_out16_f32, N, s));
+    return 0;
+}
+
 int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode, float* d_out,
                        void* stream) {
     AttnArgs a;

@@ -163,6 +163,79 @@ def test_two_term_split_is_opt_in_and_looser(hip):
     assert e3 < 2e-4 and e3 > e6   # visibly looser, still small
 
 
+# ------------------------------------------------------------------------------------------------ P16-operand GEMM
+@pytest.mark.parametrize("B,T,C,N,bm", [(3, 100, 384, 384, 0), (2, 77, 224, 100, 0), (8, 1000, 96, 1152, 128), (4, 160, 1536, 384, 64),
+                                        (1, 5, 64, 4, 0)])
+def test_p16_linear_bias_residual(hip, B, T, C, N, bm):
+    """Operands pre-split into fp16 head/residual images, tiles by LDS-DMA (csrc/gemm_p16.hip): same fp32-equivalent result."""
+    a, w, b, r = rnd(B * T, C, seed=1), rnd(N, C, seed=2, scale=C ** -0.5), rnd(N, seed=3), rnd(B * T, N, seed=4)
+    ref = F.linear(a.double(), w.double(), b.double()) + r.double()
+    o = hip.gemm_p16(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, res=r.cuda(), force_bm=bm)
+    close(o["out"], ref, 2e-6 * math.sqrt(C))
+
+
+@pytest.mark.parametrize("k,C,N,B,T", [(3, 64, 96, 2, 77), (5, 96, 160, 3, 50), (3, 224, 384, 2, 130), (5, 1152, 288, 1, 128)])
+def test_p16_conv_same_with_mask(hip, k, C, N, B, T):
+    """Implicit conv: the tap shift and the zero padding at the sequence ends are per-lane DMA source addresses; the row
+    mask is folded into the P16 image by its producer (here the conversion pass)."""
+    a, w, b = rnd(B * T, C, seed=5), rnd(N, C, k, seed=6, scale=(k * C) ** -0.5), rnd(N, seed=7)
+    lens = [T - 7 * i for i in range(B)]
+    mask = torch.zeros(B, T)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+    mask = mask.view(-1)
+    ref = conv_ref(a * mask[:, None], w, b, B, T, k // 2) * mask[:, None].double()
+    o = hip.gemm_p16(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mask=mask.cuda(), out_mask=mask.cuda())
+    close(o["out"], ref, 2e-5)
+
+
+def test_p16_conv_stride2(hip):
+    B, T, C, N = 2, 50, 64, 64
+    a, w, b = rnd(B * T, C, seed=8), rnd(N, C, 3, seed=9, scale=(3 * C) ** -0.5), rnd(N, seed=10)
+    ref = conv_ref(a, w, b, B, T, 1, stride=2)
+    o = hip.gemm_p16(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, T_out=25, in_stride=2)
+    close(o["out"], ref, 2e-5)
+
+
+@pytest.mark.parametrize("B,T", [(2, 90), (8, 1000)])
+def test_p16_layernorm_in_epilogue_snake_and_p16_output(hip, B, T):
+    """LayerNorm applied after the product as rstd * (x.W - mean * rowsum(W)) from the producer's partial moments, SnakeBeta,
+    and the result written as a P16 image for the next GEMM (decoded here): all against fp64."""
+    C, N = 384, 1536
+    a = rnd(B * T, C, seed=11) * 2 + 0.3
+    w, b = rnd(N, C, seed=12, scale=C ** -0.5), rnd(N, seed=13)
+    alpha, beta = rnd(N, seed=14, scale=0.2), rnd(N, seed=15, scale=0.2)
+    ad = a.double()
+    part = torch.stack([ad.view(-1, 6, 64).mean(-1), ((ad.view(-1, 6, 64) - ad.view(-1, 6, 64).mean(-1, keepdim=True)) ** 2).sum(-1)], -1)
+    mu = ad.mean(1)
+    var = ((ad - mu[:, None]) ** 2).mean(1)
+    h = F.linear((ad - mu[:, None]) / torch.sqrt(var + 1e-5)[:, None], w.double(), b.double())
+    ae, ib = torch.exp(alpha), 1.0 / (torch.exp(beta) + 1e-9)
+    ref = h + ib.double() * torch.sin(h * ae.double()) ** 2
+    o = hip.gemm_p16(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_part=part.float().cuda(), act=3, p0=ae.cuda(), p1=ib.cuda(),
+                     want_p16=True)
+    close(o["out"], ref, 1e-5)
+    close(o["out16"], ref, 1e-5)                       # 22 significand bits survive the image
+    mean, rstd = hip.row_stats(a.cuda())
+    o2 = hip.gemm_p16(a.cuda(), w.cuda(), b.cuda(), B=B, T_in=T, a_mean=mean, a_rstd=rstd, act=3, p0=ae.cuda(), p1=ib.cuda())
+    close(o2["out"], ref, 1e-5)
+
+
+def test_p16_stats_out_and_unscaled_residual(hip):
+    """The epilogue's 64-column partial moments, and the unscaled residual image the attention kernel reads (lscale = 1)."""
+    B, T, C = 2, 100, 384
+    a, r = rnd(B * T, C, seed=51), rnd(B * T, C, seed=52) * 2 + 0.5
+    w1, b1 = rnd(C, C, seed=53, scale=C ** -0.5), rnd(C, seed=54)
+    o = hip.gemm_p16(a.cuda(), w1.cuda(), b1.cuda(), B=B, T_in=T, res=r.cuda(), stats_out=True, want_p16=True, lscale=1.0)
+    ref = F.linear(a.double(), w1.double(), b1.double()) + r.double()
+    close(o["out"], ref, 1e-5)
+    close(o["out16"], ref, 1e-5)
+    xd = o["out"].cpu().double().view(B * T, 6, 64)
+    assert torch.allclose(o["stats"][:, :, 0].cpu().double(), xd.mean(-1), atol=1e-5)
+    assert torch.allclose(o["stats"][:, :, 1].cpu().double(), ((xd - xd.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
+
+
+
 @pytest.mark.parametrize("B,T,H,D,mode", [(2, 320, 6, 64, 0), (3, 130, 6, 48, 1), (2, 24, 2, 32, 0), (1, 77, 2, 24, 1), (1, 640, 2, 64, 0),
                                            (8, 1024, 12, 64, 0), (8, 1000, 12, 48, 1)])   # the last two run the 128-query block variant
 def test_attention(hip, oracle, B, T, H, D, mode):
