@@ -161,6 +161,11 @@ int mtts_gemm_p16(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
 int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode,
                        float* d_out, void* stream);
 
+/* mtts_attention_f32 with P16 I/O (D == 64): q|k|v read as a P16 image (unscaled residuals), output written as a P16
+ * image; here both conversions happen around the kernel, in d_scratch (>= 16*B*T*H*64 bytes). */
+int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode,
+                       float* d_out, void* d_scratch, void* stream);
+
 /* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
 int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);
 

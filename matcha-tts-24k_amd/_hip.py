@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     #   gone with scalar fp32 ops).  Packed fp32 VALU is also slower beside MFMAs (cdna_hip_programming.md).
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           *[str(s) for s in srcs], "-o", str(LIB)]
+           *os.environ.get("MTTS_HIPCC_EXTRA", "").split(), *[str(s) for s in srcs], "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -85,6 +85,7 @@ def load() -> C.CDLL:
         "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
         "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
+        "mtts_attention_p16": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp]),
         "mtts_gemm_p16_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
         "mtts_gemm_p16": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
                                 i32, vp, f32, vp, i32, vp, f32, vp, i32, vp, vp]),
@@ -366,6 +367,14 @@ def attention_f32(qkv, mask, B, T, H, D, scale, mask_mode):
     lib = load()
     out = torch.empty(B * T, H * D, dtype=torch.float32, device=qkv.device)
     check(lib.mtts_attention_f32(ptr(qkv), ptr(mask), B, T, H, D, float(scale), mask_mode, ptr(out), stream_ptr()))
+    return out
+
+
+def attention_p16(qkv, mask, B, T, H, D, scale, mask_mode):
+    lib = load()
+    out = torch.empty(B * T, H * D, dtype=torch.float32, device=qkv.device)
+    scratch = torch.empty(16 * B * T * H * D, dtype=torch.uint8, device=qkv.device)
+    check(lib.mtts_attention_p16(ptr(qkv), ptr(mask), B, T, H, D, float(scale), mask_mode, ptr(out), scratch.data_ptr(), stream_ptr()))
     return out
 
 

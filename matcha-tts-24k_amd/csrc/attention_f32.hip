@@ -40,7 +40,10 @@ __device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2
 
 // NW waves per workgroup = NW*32 queries.  NW = 4 for long sequences; NW = 2 when T is short enough that 128-query
 // blocks would leave the last block mostly empty or the grid under one round (e.g. T = 320: 3 blocks of 128 waste 17 %).
-template <int NW>
+// P16: q|k|v rows arrive as a P16 image with UNSCALED residuals (written by the q|k|v projection's epilogue, gemm_p16.hip)
+// and the output leaves as a P16 image with the 2^11-scaled residual for the out-projection: no split arithmetic on the
+// way in, one per output element on the way out.  Head dim 64 only (a head = 256 contiguous bytes of the row).
+template <int NW, bool P16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
@@ -77,6 +80,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     bool q_ok = q_in;
     if (p.mask_mode == 1 && q_in) q_ok = p.mask[rowbase + qi] != 0.f;
     f16x8 qh[4], ql[4];
+    const _Float16* q16 = p.qkv16 + head * (2 * AT_D);                       // head h = groups 2h, 2h+1 of the q section
+    const _Float16* k16 = q16 + 2 * p.H * AT_D;
+    const _Float16* v16 = q16 + 4 * p.H * AT_D;
+    if constexpr (P16) {
+        const _Float16* qrow = q16 + (rowbase + (q_in ? qi : 0)) * (size_t)p.ld16;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const _Float16* src = qrow + (kb >> 1) * 64 + (kb & 1) * 16 + 8 * h;
+            qh[kb] = q_in ? *reinterpret_cast<const f16x8*>(src) : z;
+            ql[kb] = q_in ? *reinterpret_cast<const f16x8*>(src + 32) : z;
+        }
+    } else
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -103,7 +119,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     // ---- staging: thread -> key row (tid>>2) + SROWS*pass, float4 columns (tid&3)*4 + 16c: 4 lanes read 64 contiguous bytes
     const int srow = tid >> 2;
     const int sd = (tid & 3) * 4;
-    f32x4 rk[SP][4], rv[SP][4];
+    f32x4 rk[SP][4], rv[SP][4];       // P16: the same 16 bytes hold 8 halves (chunk (tid&3) + 4c of the head's 256-B slice)
     float rbias[SP];
     bool r_in[SP];
     // all loads unconditional (clamped addresses), zeroing deferred to the LDS write: nothing waits inside the fetch
@@ -115,10 +131,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
             const size_t row = rowbase + (r_in[sp] ? key : 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int d = sd + 16 * c;
-                const int dd = d < p.D ? d : 0;
-                rk[sp][c] = *reinterpret_cast<const f32x4*>(kptr + row * ld + dd);
-                rv[sp][c] = *reinterpret_cast<const f32x4*>(vptr + row * ld + dd);
+                if constexpr (P16) {
+                    rk[sp][c] = *reinterpret_cast<const f32x4*>(k16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
+                    rv[sp][c] = *reinterpret_cast<const f32x4*>(v16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
+                } else {
+                    const int d = sd + 16 * c;
+                    const int dd = d < p.D ? d : 0;
+                    rk[sp][c] = *reinterpret_cast<const f32x4*>(kptr + row * ld + dd);
+                    rv[sp][c] = *reinterpret_cast<const f32x4*>(vptr + row * ld + dd);
+                }
             }
             rbias[sp] = p.mask ? p.mask[row] : 1.0f;
         }
@@ -128,6 +149,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
         for (int sp = 0; sp < SP; ++sp) {
             const int r = srow + SROWS * sp;
+            if constexpr (P16) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {      // chunk (tid&3) + 4c: plane c&1 (head / residual), dims 32 (c>>1) + 8 (tid&3) ..+7
+                    const int plane = c & 1, d = 32 * (c >> 1) + 8 * (tid & 3);
+                    const f32x4 kraw = r_in[sp] ? rk[sp][c] : zero;
+                    *reinterpret_cast<f32x4*>(Ks + plane * AT_K * AT_KS + r * AT_KS + d) = kraw;
+                    const f32x4 vraw = r_in[sp] ? rv[sp][c] : zero;
+                    const f16x8 vv = __builtin_bit_cast(f16x8, vraw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Vt[plane * AT_D * AT_VS + (d + e) * AT_VS + r] = vv[e];   // transposing 16-bit stores
+                }
+            } else
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const bool ok = r_in[sp] && (sd + 16 * c) < p.D;
@@ -245,7 +278,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     // ---- normalise and store: lane holds query qi; register r of d-tile t is d = 32t + (r&3) + 8(r>>2) + 4h
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (q_in) {
+    if (P16) {
+        if (q_in) {
+            _Float16* op = p.out16 + (rowbase + qi) * (size_t)p.ldo16 + head * (2 * AT_D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f16x4 hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[t][4 * g4 + e] * inv;
+                        hh[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+                        ll[e] = (_Float16)fminf(fmaxf((v - (float)hh[e]) * p.out_lscale, -65504.f), 65504.f);
+                    }
+                    *reinterpret_cast<f16x4*>(op + t * 64 + 8 * g4 + 4 * h) = hh;
+                    *reinterpret_cast<f16x4*>(op + t * 64 + 32 + 8 * g4 + 4 * h) = ll;
+                }
+        }
+    } else if (q_in) {
         float* op = p.out + (rowbase + qi) * (size_t)(p.H * p.D) + head * p.D;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -261,7 +312,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 }
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    if (!a.qkv || !a.out || a.B <= 0 || a.T <= 0 || a.H <= 0) return hipErrorInvalidValue;
+    const bool p16 = a.qkv16 != nullptr;
+    if (p16 ? (!a.out16 || a.D != AT_D || a.ld16 < 6 * a.H * AT_D || (a.ld16 & 7) || a.ldo16 < 2 * a.H * AT_D || (a.ldo16 & 3))
+            : (!a.qkv || !a.out))
+        return hipErrorInvalidValue;
+    if (a.B <= 0 || a.T <= 0 || a.H <= 0) return hipErrorInvalidValue;
     if (a.D <= 0 || a.D > AT_D || (a.D & 3)) return hipErrorInvalidValue;
     if (a.mask_mode == 1 && !a.mask) return hipErrorInvalidValue;
     // 128-query blocks when they fill at least ~1.5 rounds of the chip without much tail waste, else 64-query blocks
@@ -269,9 +324,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const long blocks128 = (long)b128 * a.H * a.B;
     const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
     if (blocks128 >= 768 && waste128 < 0.1) {
-        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(attention_f32_kernel<2>, dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        if (p16) hipLaunchKernelGGL((attention_f32_kernel<2, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((attention_f32_kernel<2, false>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
     }
     return hipGetLastError();
 }

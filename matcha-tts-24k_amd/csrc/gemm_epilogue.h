@@ -1,0 +1,121 @@
+// Shared GEMM epilogue (gemm_f32.hip, gemm_p16.hip): the wave's BM/2 x 64 tile is parked in LDS (row stride GEMM_CS
+// floats) and re-read as rows of float4, 16 lanes per row, so every store instruction writes whole 256-byte row pieces.
+//
+//   c = act(LN'(acc) + bias);  c *= out_mask[row];  c *= out_scale;  c += res[row][n]
+//   -> fp32 rows (out) and/or a P16 image (out16); optional 64-column partial moments (stats_out)
+//
+// Built for memory-level parallelism: the tile's rows go in chunks of 16 with no early exits, a chunk's residual rows and
+// mask values are all requested BEFORE the first one is consumed, and the activation / residual choice is made once per
+// kernel (wave-uniform dispatch into compile-time variants) instead of per element.  The previous form (a rolled loop: LDS read -> residual load -> wait -> store, an activation switch per
+// element) cost 20-50 us per launch on the decoder's shapes (tools/p16_ablate.py).
+#pragma once
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace mtts {
+
+constexpr int GEMM_CS = 68;   // row stride of the parked tile (floats)
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+// LN: LayerNorm-in-the-epilogue (P16 kernel): srow = [BM means | BM rstds] in LDS, p.wsum = panel row sums.
+template <int BM, bool LN>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
+                                                   int M, int m0, int n0, int wm, int wn, int lane) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+    constexpr int NIT = BM / 8;                              // rows per lane: 4 rows per pass x NIT passes
+    const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+    const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns
+    const bool col_ok = nc < p.N;                            // N % 4 == 0: a lane's 4 columns are in or out together
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, s0 = bias4, s1 = bias4, ws4 = bias4;
+    if (col_ok) {
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        if (p.act == ACT_SNAKE) { s0 = *reinterpret_cast<const f32x4*>(p.p0 + nc); s1 = *reinterpret_cast<const f32x4*>(p.p1 + nc); }
+        if (LN) ws4 = *reinterpret_cast<const f32x4*>(p.wsum + nc);
+    }
+    auto run = [&](auto act_c, auto res_c) {
+        constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
+        constexpr bool RES = decltype(res_c)::value != 0;
+        // chunks of U passes (4 U rows of the tile): all of a chunk's residual / mask loads are in flight together
+        constexpr int U = 4;
+        for (int c0 = 0; c0 < NIT; c0 += U) {
+            int orow[U];
+            bool ok[U];
+            float om[U];
+            f32x4 rres[RES ? U : 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + wm * (BM / 2) + (c0 + u) * 4 + (lane >> 4);
+                ok[u] = m < M && col_ok;
+                const int mc = m < M ? m : M - 1;
+                int r = mc;
+                if (!plain_rows) {
+                    const int b = mc / p.T_out;
+                    r = b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
+                }
+                orow[u] = r;
+                om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
+                if constexpr (RES) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = (c0 + u) * 4 + (lane >> 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * GEMM_CS + (lane & 15) * 4);
+                f32x4 o;
+                if constexpr (LN) {
+                    const float mean = srow[wm * (BM / 2) + rl], rstd = srow[BM + wm * (BM / 2) + rl];
+                    o = (a - mean * ws4) * rstd + bias4;
+                } else {
+                    o = a + bias4;
+                }
+                if constexpr (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] + s1[e] * sin_sq(o[e] * s0[e]);     // SnakeBeta, reference transformer.py:75
+                } else if constexpr (ACT == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], p.act, s0[e], s1[e]);
+                }
+                o *= om[u];
+                if (p.out_scale != 1.0f) o *= p.out_scale;
+                if constexpr (RES) o += rres[u];
+                if (ok[u]) {
+                    if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)orow[u] * p.ldc + nc) = o;
+                    if (p.out16) {                           // P16 copy: 8 lanes write one whole 128-B line
+                        f16x4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = (_Float16)fminf(fmaxf(o[e], -65504.f), 65504.f);
+                            l[e] = (_Float16)fminf(fmaxf((o[e] - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
+                        }
+                        _Float16* o16 = p.out16 + (size_t)orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
+                        *reinterpret_cast<f16x4*>(o16) = h;
+                        *reinterpret_cast<f16x4*>(o16 + 32) = l;
+                    }
+                }
+                if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row (N % 64 == 0): the 16 lanes lane&15 hold them
+                    const float mu = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
+                    const f32x4 d = o - mu;
+                    const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                    if ((lane & 15) == 0 && ok[u]) {
+                        float* so = p.stats_out + ((size_t)orow[u] * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                        so[0] = mu;
+                        so[1] = m2;
+                    }
+                }
+            }
+        }
+    };
+    const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
+    if (p.res) {
+        if (actk == 0) run(IntC<0>{}, IntC<1>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<1>{});
+        else run(IntC<2>{}, IntC<1>{});
+    } else {
+        if (actk == 0) run(IntC<0>{}, IntC<0>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<0>{});
+        else run(IntC<2>{}, IntC<0>{});
+    }
+}
+
+}  // namespace mtts

@@ -31,6 +31,7 @@
 //      range (|x| > 65504) saturate instead of overflowing.
 #include "kernels.h"
 #include "device_utils.h"
+#include "gemm_epilogue.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
     // ---- epilogue.  Accumulator map (32x32 tile): column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Each wave parks its 64x64 tile in LDS (free after the last barrier) and re-reads it as float4 rows, so that the
     // epilogue math runs on 4 consecutive columns per lane and every store instruction writes whole 256-byte row pieces.
-    constexpr int CS = 68;   // row stride of the parked tile (floats)
+    constexpr int CS = GEMM_CS;   // row stride of the parked tile (floats)
     float* Cw = lds + wave * ((BM / 2) * CS);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -378,6 +379,11 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns
     const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    if (vec) {     // the common case: unrolled, residuals prefetched, activation chosen once (gemm_epilogue.h)
+        gemm_epilogue_rows<BM, false>(p, Cw, nullptr, M, m0, n0, wm, wn, lane);
+        return;
+    }
+    // odd widths (N or a leading dimension not a multiple of 4: the 1-channel duration head, 100-bin mel rows): scalar stores
     float bias4[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -406,25 +412,9 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
             c[e] = v;
         }
         float* op = p.out + (size_t)orow * p.ldc + nc;
-        if (vec) {
-            f32x4 o = {c[0], c[1], c[2], c[3]};
-            if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)orow * p.ldr + nc);
-            *reinterpret_cast<f32x4*>(op) = o;
-            if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 16 lanes lane&15 hold them
-                const float mean = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
-                const f32x4 d = o - mean;
-                const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
-                if ((lane & 15) == 0) {
-                    float* so = p.stats_out + ((size_t)orow * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
-                    so[0] = mean;
-                    so[1] = m2;
-                }
-            }
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (nc + e < p.N) op[e] = p.res ? c[e] + p.res[(size_t)orow * p.ldr + nc + e] : c[e];
-        }
+        for (int e = 0; e < 4; ++e)
+            if (nc + e < p.N) op[e] = p.res ? c[e] + p.res[(size_t)orow * p.ldr + nc + e] : c[e];
     }
 }
 

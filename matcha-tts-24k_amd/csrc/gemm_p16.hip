@@ -18,6 +18,7 @@
 // Replaces, like gemm_f32.hip: nn.Linear / nn.Conv1d of the reference decoder (decoder.py, transformer.py) on the hot path.
 #include "kernels.h"
 #include "device_utils.h"
+#include "gemm_epilogue.h"
 
 namespace mtts {
 
@@ -28,7 +29,7 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 __device__ __attribute__((aligned(128))) _Float16 g_p16_zero_line[64];     // source of out-of-range conv taps (zero-initialised)
 
-constexpr int P16_CS = 68;                                                  // epilogue tile row stride (floats)
+constexpr int P16_CS = GEMM_CS;                                             // epilogue tile row stride (floats)
 constexpr int p16_stage_bytes(int BM) { return (BM + GEMM_BN) * 128; }
 constexpr int p16_epi_bytes(int BM) { return 4 * (BM / 2) * P16_CS * 4; }
 constexpr int p16_main_bytes(int BM) { return 2 * p16_stage_bytes(BM) > p16_epi_bytes(BM) ? 2 * p16_stage_bytes(BM) : p16_epi_bytes(BM); }
@@ -59,27 +60,6 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     const int m0 = (swz / n_tiles) * BM;
     const int n0 = (swz % n_tiles) * GEMM_BN;
 
-    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue
-    if (LN) {
-        if (tid < BM) {
-            const int row = min(m0 + tid, M - 1);
-            float mean, rstd;
-            if (p.a_part) {
-                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
-                float sm = 0.f, m2 = 0.f;
-                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
-                mean = sm / (float)p.a_nparts;
-                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
-                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
-            } else {
-                mean = p.a_mean[row];
-                rstd = p.a_rstd[row];
-            }
-            srow[tid] = mean;
-            srow[BM + tid] = rstd;
-        }
-    }
-
     // ---- DMA coordinates.  Piece pa of the A tile = rows 8 pa .. 8 pa + 7; lane i fills LDS bytes [16 i, 16 i + 16) of the
     // piece = row i>>3, slot i&7, which must hold chunk (i&7) ^ ((row>>1)&7), row>>1 = 4 pa + (i>>4).
     int a_base[APW], a_t[APW], a_chunk[APW];
@@ -104,26 +84,43 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         const int chunk = (lane & 7) ^ (((pw & 1) * 4 + (lane >> 4)) & 7);
         wsrc[j] = reinterpret_cast<const _Float16*>(p.w16) + (size_t)(n0 + pw * 8 + (lane >> 3)) * Kp * 2 + chunk * 8;
     }
-    int ld_tap = 0, ld_c = 0, ld_k = 0;    // (tap, channel, k-step) of the next tile to request
-    auto issue = [&](int buf) {
-        char* st = lds + buf * STAGE;
-        const bool seg1 = p.a16_1 != nullptr && ld_c >= p.c0;           // wave-uniform
+    // The K axis is a sequence of runs, one per (tap, channel segment); inside a run every k-step only advances the source
+    // pointers by one 128-B group, so the per-lane address arithmetic (tap shift, sequence bounds, segment base) is done once
+    // per run and the loop body is pointer bumps + DMA issue.
+    const _Float16* asrc[APW];
+    int astep[APW];
+    int run_tap = 0, run_seg = 0, run_left = 0;
+    auto setup_run = [&]() {
+        const bool seg1 = run_seg == 1;                                  // wave-uniform
         const _Float16* src = seg1 ? p.a16_1 : p.a16_0;
         const int ld = seg1 ? p.lda16_1 : p.lda16_0;
-        const int goff = ((seg1 ? ld_c - p.c0 : ld_c) >> 5) * 64;
-        const int off = p.tap_off[ld_tap];
+        const int off = p.tap_off[run_tap];
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
             const int tin = a_t[j] + off;
             const bool ok = (unsigned)tin < (unsigned)p.T_in;
-            const _Float16* gp = ok ? src + (size_t)(a_base[j] + tin) * ld + goff + a_chunk[j] : g_p16_zero_line + a_chunk[j];
-            MTTS_GLDS16(gp, st + (wave * APW + j) * 1024);
+            asrc[j] = ok ? src + (size_t)(a_base[j] + tin) * ld + a_chunk[j] : g_p16_zero_line + a_chunk[j];
+            astep[j] = ok ? 64 : 0;                                      // the zero line is re-read, not walked
+        }
+        run_left = (seg1 ? p.c1 : p.c0) >> 5;
+    };
+    auto issue = [&](int buf) {
+        char* st = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            MTTS_GLDS16(asrc[j], st + (wave * APW + j) * 1024);
+            asrc[j] += astep[j];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) MTTS_GLDS16(wsrc[j] + (size_t)ld_k * 64, st + BM * 128 + (wave * 4 + j) * 1024);
-        ld_c += GEMM_BK;
-        ++ld_k;
-        if (ld_c >= p.ktap) { ld_c = 0; ++ld_tap; }
+        for (int j = 0; j < 4; ++j) {
+            MTTS_GLDS16(wsrc[j], st + BM * 128 + (wave * 4 + j) * 1024);
+            wsrc[j] += 64;
+        }
+        if (--run_left == 0) {                                           // next run: other segment, then next tap
+            if (run_seg == 0 && p.a16_1 != nullptr) run_seg = 1;
+            else { run_seg = 0; ++run_tap; }
+            if (run_tap < p.ntaps) setup_run();
+        }
     };
 
     f32x16 acc[MI][2], accx[MI][2];
@@ -137,7 +134,30 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     // fragment of v_mfma_f32_32x32x16_f16: lane (r = lane&31, h = lane>>5) holds k = 8h .. 8h+7 of a 16-wide k block
     const int fr = lane & 31, fh = lane >> 5, f8 = (fr >> 1) & 7;
     const int nk = Kp / GEMM_BK;
+    setup_run();
     issue(0);
+    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
+    // the first tile's flight
+    if (LN) {
+        if (tid < BM) {
+            const int row = min(m0 + tid, M - 1);
+            float mean, rstd;
+            if (p.a_part) {
+                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
+                float sm = 0.f, m2 = 0.f;
+                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                mean = sm / (float)p.a_nparts;
+                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
+            } else {
+                mean = p.a_mean[row];
+                rstd = p.a_rstd[row];
+            }
+            srow[tid] = mean;
+            srow[BM + tid] = rstd;
+        }
+    }
+
     __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -182,65 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
     __builtin_amdgcn_wave_barrier();
 
-    const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
-    const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns (N % 4 == 0 is required)
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, ws4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nc < p.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (p.bias) bias4[e] = p.bias[nc + e];
-            if (p.act == ACT_SNAKE) { s0[e] = p.p0[nc + e]; s1[e] = p.p1[nc + e]; }
-            if (LN) ws4[e] = p.wsum[nc + e];
-        }
-    }
-    for (int it = 0; it < BM / 8; ++it) {
-        const int rl = it * 4 + (lane >> 4);
-        const int m = m0 + wm * (BM / 2) + rl;
-        if (m >= M || nc >= p.N) continue;
-        int orow = m;
-        if (!plain_rows) {
-            const int b = m / p.T_out;
-            orow = b * p.out_T + (m - b * p.T_out) * p.out_stride + p.out_off;
-        }
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * P16_CS + (lane & 15) * 4);
-        float mean = 0.f, rstd = 1.f;
-        if (LN) { mean = srow[wm * (BM / 2) + rl]; rstd = srow[BM + wm * (BM / 2) + rl]; }
-        const float om = p.out_mask ? p.out_mask[orow] : 1.0f;
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = a[e];
-            if (LN) v = rstd * (v - mean * ws4[e]);
-            v = act_apply(v + bias4[e], p.act, s0[e], s1[e]);
-            if (p.out_mask) v *= om;
-            if (p.out_scale != 1.0f) v *= p.out_scale;
-            o[e] = v;
-        }
-        if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)orow * p.ldr + nc);
-        if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)orow * p.ldc + nc) = o;
-        if (p.out16) {                     // P16 copy for the next GEMM / attention: 8 lanes write one whole 128-B line
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xc = fminf(fmaxf(o[e], -65504.f), 65504.f);
-                h[e] = (_Float16)xc;
-                l[e] = (_Float16)fminf(fmaxf((o[e] - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
-            }
-            _Float16* o16 = p.out16 + (size_t)orow * p.ld16 + (nc >> 5) * 64 + (nc & 31);
-            *reinterpret_cast<f16x4*>(o16) = h;
-            *reinterpret_cast<f16x4*>(o16 + 32) = l;
-        }
-        if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 16 lanes lane&15 hold them
-            const float mu = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
-            const f32x4 d = o - mu;
-            const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
-            if ((lane & 15) == 0) {
-                float* so = p.stats_out + ((size_t)orow * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
-                so[0] = mu;
-                so[1] = m2;
-            }
-        }
-    }
+    gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane);
 }
 
 template <int BM, bool LN>

@@ -97,6 +97,10 @@ struct AttnArgs {
     int B = 0, T = 0, H = 0, D = 0;
     float scale = 1.0f;
     int mask_mode = 0;            // 0 additive key bias, 1 boolean query*key
+    // P16 I/O (D == 64): q|k|v as a P16 image with unscaled residuals, output as a P16 image (residual times out_lscale)
+    const _Float16* qkv16 = nullptr; int ld16 = 0;     // row stride in halves (>= 6*H*64)
+    _Float16* out16 = nullptr; int ldo16 = 0;          // row stride in halves (>= 2*H*64)
+    float out_lscale = 2048.0f;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
@@ -131,6 +135,8 @@ struct GnApplyArgs {
     const float* res = nullptr; int ldr = 0;
     float* out = nullptr;
     float* stats_out = nullptr;       // [B*T][C/64][2] LayerNorm partial moments of the output rows (C % 64 == 0)
+    _Float16* out16 = nullptr;        // optional P16 copy of the output rows (C % 32 == 0), row stride ld16 halves
+    int ld16 = 0;
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

@@ -18,6 +18,7 @@ struct Panel {
     size_t w = 0, b = 0;
     size_t w16 = 0;            // bf16 split planes [3][Np][Kp] (offset in floats), present when the context uses a split mode
     bool has_bias = false;
+    size_t wsum = 0;           // [Np] row sums of the panel (fp16-split mode): LayerNorm in the P16 GEMM's epilogue
     int N = 0, C = 0, ntaps = 1, ktap = 0;
 };
 struct Vec { size_t off = 0; int n = 0; };

@@ -120,8 +120,17 @@ struct Packer {
         if (c->gemm_terms == 0) return;
         const size_t n = (size_t)round_up(p.N, GEMM_BN) * p.ntaps * p.ktap;
         p.w16 = alloc((3 * n + 1) / 2);
-        if (c->gemm_terms == 2) split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
-        else split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+        if (c->gemm_terms == 2) {
+            split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+            const int Np = round_up(p.N, GEMM_BN);
+            const size_t Kp = (size_t)p.ntaps * p.ktap;
+            p.wsum = alloc(Np);
+            for (int r = 0; r < Np; ++r) {
+                double acc = 0.0;
+                for (size_t k = 0; k < Kp; ++k) acc += (double)c->image[p.w + (size_t)r * Kp + k];
+                c->image[p.wsum + r] = (float)acc;
+            }
+        } else split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
     }
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
@@ -348,6 +357,7 @@ static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
     a.terms = c->gemm_terms;
     a.w16 = c->gemm_terms ? static_cast<const void*>(W(c, p.w16)) : nullptr;
     a.bias = p.has_bias ? W(c, p.b) : nullptr;
+    a.wsum = c->gemm_terms == 2 ? W(c, p.wsum) : nullptr;
     a.N = p.N;
     a.ntaps = p.ntaps;
     a.ktap = p.ktap;
@@ -368,6 +378,7 @@ struct DecBufs {
     std::vector<float*> bufA, bufB, skip;
     float *Y = nullptr, *Hh = nullptr, *Rr = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
     float *mean = nullptr, *rstd = nullptr, *gnp = nullptr, *lnp = nullptr;
+    _Float16* X16 = nullptr;             // P16 image of the residual stream x (the LayerNorm'd projections' LDS-DMA source)
     float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
     float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
     int ldx = 0, ldv = 0;
@@ -395,6 +406,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     d.QKV = ws.f(M0 * 3 * inner); d.ATT = ws.f(M0 * inner); d.FF = ws.f(M0 * 4 * cmax);
     d.mean = ws.f(M0); d.rstd = ws.f(M0);
     d.lnp = ws.f(M0 * (size_t)((cmax + 63) / 64) * 2);
+    d.X16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(cmax, 32)));
     d.gnp = ws.f((size_t)B * gn_chunks(T) * 8 * 2);
     d.ldx = round_up(2 * g.n_feats, GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
@@ -431,6 +443,14 @@ static int time_embed(mtts_ctx* c, DecBufs& d, const TimeVals& tv, int nt, hipSt
     return 0;
 }
 
+// Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
+// fp16-split mode and the shapes allow whole 32-channel groups and 64-wide heads; MTTS_P16=0 keeps the fp32-operand path.
+static bool p16_blocks(const mtts_ctx* c, int C) {
+    static const bool env_on = [] { const char* e = getenv("MTTS_P16"); return !(e && e[0] == '0'); }();
+    const mtts_config& g = c->cfg;
+    return env_on && c->gemm_terms == 2 && (C % 64) == 0 && g.dec_head_dim == 64;
+}
+
 // ResnetBlock1D.forward (reference decoder.py:58-63) on channels-last rows; input = up to two channel segments.
 static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* in0, int ld0, int c0, const float* in1, int ld1,
                         int c1, int lvl, const float* tbias, float* out, bool emit_stats, hipStream_t s) {
@@ -459,7 +479,10 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
     GnApplyArgs g2;
     g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask;
     g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
-    if (emit_stats && (C % 64) == 0) g2.stats_out = d.lnp;      // LayerNorm moments for the first transformer block
+    if (emit_stats && (C % 64) == 0) {       // for the first transformer block: LayerNorm moments and, in P16 mode, x's image
+        g2.stats_out = d.lnp;
+        if (p16_blocks(c, C)) { g2.out16 = d.X16; g2.ld16 = 2 * C; }
+    }
     LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
     return 0;
 }
@@ -474,6 +497,39 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
     const mtts_config& g = c->cfg;
     const int B = d.B, T = d.Tl[lvl], M = B * T, inner = g.dec_heads * g.dec_head_dim;
     const bool fuse = (C % 64) == 0;
+    if (p16_blocks(c, C) && have_stats) {
+        // P16 flow: q|k|v, the attention output and the FF hidden layer exist only as P16 images (same bytes as fp32, in the
+        // same buffers); x stays fp32 (the residual stream) with a P16 copy for the two LayerNorm'd projections.
+        _Float16* QKV16 = reinterpret_cast<_Float16*>(d.QKV);
+        _Float16* ATT16 = reinterpret_cast<_Float16*>(d.ATT);
+        _Float16* FF16 = reinterpret_cast<_Float16*>(d.FF);
+        GemmArgs q;
+        panel_args(c, t.qkv, q); rows_plain(q, B, T);
+        q.a16_0 = d.X16; q.lda16_0 = 2 * C; q.c0 = C; q.a_part = d.lnp; q.a_nparts = C / 64;
+        q.out16 = QKV16; q.ld16 = 6 * inner; q.out_lscale = 1.0f;
+        RET_IF(run_gemm(c, q, s));
+        AttnArgs at;
+        at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.mask[lvl];
+        at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
+        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0;
+        RET_IF(run_attn(c, at, s));
+        GemmArgs o;
+        panel_args(c, t.out, o); rows_plain(o, B, T);
+        o.a16_0 = ATT16; o.lda16_0 = 2 * inner; o.c0 = inner; o.res = x; o.ldr = C; o.out = x; o.ldc = C;
+        o.out16 = d.X16; o.ld16 = 2 * C; o.stats_out = d.lnp;
+        RET_IF(run_gemm(c, o, s));
+        GemmArgs f1;
+        panel_args(c, t.ff1, f1); rows_plain(f1, B, T);
+        f1.a16_0 = d.X16; f1.lda16_0 = 2 * C; f1.c0 = C; f1.a_part = d.lnp; f1.a_nparts = C / 64; f1.act = ACT_SNAKE;
+        f1.p0 = W(c, t.alpha_exp.off); f1.p1 = W(c, t.inv_beta.off); f1.out16 = FF16; f1.ld16 = 8 * C;
+        RET_IF(run_gemm(c, f1, s));
+        GemmArgs f2;
+        panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
+        f2.a16_0 = FF16; f2.lda16_0 = 8 * C; f2.c0 = 4 * C; f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C;
+        if (emit_stats) { f2.stats_out = d.lnp; f2.out16 = d.X16; f2.ld16 = 2 * C; }
+        RET_IF(run_gemm(c, f2, s));
+        return 0;
+    }
     GemmArgs q;
     panel_args(c, t.qkv, q); rows_plain(q, B, T);
     q.a0 = x; q.lda0 = C; q.c0 = C; q.out = d.QKV; q.ldc = 3 * inner;
@@ -1015,6 +1071,24 @@ int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, in
     AttnArgs a;
     a.qkv = d_qkv; a.mask = d_mask; a.out = d_out; a.B = B; a.T = T; a.H = H; a.D = D; a.scale = scale; a.mask_mode = mask_mode;
     HIP_OK(launch_attention(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// Test entry for the attention kernel's P16 I/O: q|k|v converted to a P16 image with unscaled residuals in d_scratch
+// (>= 16*B*T*H*64 bytes), the P16 output decoded back to fp32.  D must be 64.
+int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode, float* d_out,
+                       void* d_scratch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D != 64 || !d_scratch) { set_error("P16 attention needs D == 64 and a scratch buffer"); return -1; }
+    const int M = B * T, C3 = 3 * H * D;
+    _Float16* q16 = static_cast<_Float16*>(d_scratch);
+    _Float16* o16 = q16 + (size_t)M * 2 * C3;
+    HIP_OK(launch_to_p16(d_qkv, C3, nullptr, M, C3, q16, 2 * C3, 1.0f, s));
+    AttnArgs a;
+    a.qkv16 = q16; a.ld16 = 2 * C3; a.out16 = o16; a.ldo16 = 2 * H * D; a.mask = d_mask;
+    a.B = B; a.T = T; a.H = H; a.D = D; a.scale = scale; a.mask_mode = mask_mode;
+    HIP_OK(launch_attention(a, s));
+    HIP_OK(launch_from_p16(o16, 2 * H * D, M, H * D, a.out_lscale, d_out, H * D, s));
     return 0;
 }
 

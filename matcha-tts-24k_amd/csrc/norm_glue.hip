@@ -230,6 +230,18 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
         if (p.chbias) o = (o + cb) * mk;
         if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + c4 * 4);
         *reinterpret_cast<f32x4*>(p.out + row * p.C + c4 * 4) = o;
+        if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
+            using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+            f16x4 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hh[e] = (_Float16)fminf(fmaxf(o[e], -65504.f), 65504.f);
+                ll[e] = (_Float16)fminf(fmaxf((o[e] - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
+            }
+            _Float16* o16 = p.out16 + row * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
+            *reinterpret_cast<f16x4*>(o16) = hh;
+            *reinterpret_cast<f16x4*>(o16 + 32) = ll;
+        }
         if (p.stats_out) {   // LayerNorm partial moments of the row's 64-column slices (16 threads = one DPP row each), as the
                              // GEMM epilogue leaves them (gemm_f32.hip): the first transformer block needs no row_stats pass
             const float mean = gn_allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
@@ -250,6 +262,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
+    if (a.out16 && ((a.C & 31) || a.ld16 < 2 * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.T), a.B), gn_block(a.C), 0, s, a);
     return hipGetLastError();
 }

@@ -256,6 +256,32 @@ def test_attention(hip, oracle, B, T, H, D, mode):
     close(out, ref, 5e-6)
 
 
+@pytest.mark.parametrize("B,T,H,mode", [(2, 320, 6, 0), (1, 640, 2, 0), (3, 130, 2, 1), (32, 640, 6, 0)])
+def test_attention_p16_io(hip, oracle, B, T, H, mode):
+    """Same kernel with q|k|v read from a P16 image and the output written as one (the decoder's transformer blocks)."""
+    D = 64
+    qkv = rnd(B * T, 3 * H * D, seed=22)
+    lens = torch.tensor([T - 3 * i for i in range(B)])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()
+    out = hip.attention_p16(qkv.cuda(), mask.reshape(-1).cuda(), B, T, H, D, 0.125, mode)
+    ref = hip.attention_f32(qkv.cuda(), mask.reshape(-1).cuda(), B, T, H, D, 0.125, mode)      # itself checked against fp64 above
+    if mode == 1:
+        keep = mask.reshape(-1).bool().cuda()
+        out, ref = out[keep], ref[keep]
+    assert (out - ref).abs().max().item() < 2e-6
+    if B <= 3:
+        q, k, v = [z.view(B, T, H, D).transpose(1, 2).double() for z in qkv.split(H * D, dim=1)]
+        if mode == 0:
+            r64 = oracle.sdpa_reference(q, k, v, mask.double().view(B, 1, 1, T).expand(B, H, 1, T), 0.125)
+        else:
+            r64 = oracle.sdpa_reference(q, k, v, (mask[:, None, :, None] * mask[:, None, None, :]).bool(), 0.125)
+        r64 = r64.transpose(1, 2).reshape(B * T, H * D)
+        o = out.cpu()
+        if mode == 1:
+            r64 = r64[mask.reshape(-1).bool()]
+        close(o, r64, 5e-6)
+
+
 def test_attention_forced_rescale(hip, oracle):
     """One key per tile dominates so that the running max jumps at every tile boundary (online-softmax rescale path)."""
     B, T, H, D = 1, 256, 1, 64
