@@ -2,7 +2,8 @@
 // floats) and re-read as rows of float4, 16 lanes per row, so every store instruction writes whole 256-byte row pieces.
 //
 //   c = act(LN'(acc) + bias);  c *= out_mask[row];  c *= out_scale;  c += res[row][n]
-//   -> fp32 rows (out) and/or a P16 image (out16); optional 64-column partial moments (stats_out)
+//   -> fp32 rows (out) and/or a P16 image (out16, optionally times out16_mask[row]); optional 64-column partial moments
+//      (stats_out)
 //
 // Built for memory-level parallelism: the tile's rows go in chunks of 16 with no early exits, a chunk's residual rows and
 // mask values are all requested BEFORE the first one is consumed, and the activation / residual choice is made once per
@@ -42,7 +43,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         for (int c0 = 0; c0 < NIT; c0 += U) {
             int orow[U];
             bool ok[U];
-            float om[U];
+            float om[U], om16[U];
             f32x4 rres[RES ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -56,6 +57,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 }
                 orow[u] = r;
                 om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
+                om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
                 if constexpr (RES) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
             }
 #pragma unroll
@@ -85,8 +87,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                         f16x4 h, l;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            h[e] = (_Float16)fminf(fmaxf(o[e], -65504.f), 65504.f);
-                            l[e] = (_Float16)fminf(fmaxf((o[e] - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
+                            const float v = o[e] * om16[u];
+                            h[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+                            l[e] = (_Float16)fminf(fmaxf((v - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
                         }
                         _Float16* o16 = p.out16 + (size_t)orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
                         *reinterpret_cast<f16x4*>(o16) = h;

@@ -253,13 +253,14 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 <-> P16
-__global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C,
+__global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C, int C_valid,
                               _Float16* __restrict__ out, int ld16, float lscale) {
     const int c4n = C >> 2;
     const size_t n = (size_t)M * c4n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / c4n), c = (int)(i - (size_t)row * c4n) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + c);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < C_valid) v = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + c);     // C_valid % 4 == 0
         if (mask) v *= mask[row];
         f16x4 h, l;
 #pragma unroll
@@ -272,12 +273,14 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
         *reinterpret_cast<f16x4*>(o + 32) = l;
     }
 }
-hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, _Float16* out, int ld16, float lscale, hipStream_t s) {
-    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || ld < C || ld16 < 2 * C || (ld16 & 3)) return hipErrorInvalidValue;
+hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
+                         hipStream_t s) {
+    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || C_valid > C || (C_valid & 3) || ld < C_valid || ld16 < 2 * C || (ld16 & 3))
+        return hipErrorInvalidValue;
     const size_t n = (size_t)M * (C >> 2);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, out, ld16, lscale);
+    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale);
     return hipGetLastError();
 }
 __global__ void from_p16_kernel(const _Float16* __restrict__ x, int ld16, int M, int C, float inv_lscale, float* __restrict__ out, int ld) {

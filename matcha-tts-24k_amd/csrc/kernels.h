@@ -64,11 +64,13 @@ struct GemmArgs {
     _Float16* out16 = nullptr;        // optional P16 copy of the output (N % 32 == 0)
     int ld16 = 0;                     // its row stride in halves
     float out_lscale = 2048.0f;       // residual scale of out16: 2048 for GEMM operands, 1 for the attention kernel's q|k|v
+    const float* out16_mask = nullptr;// [rows] multiplies the out16 copy only (conv consumers read masked rows; out stays as is)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
 // fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
-hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, _Float16* out, int ld16, float lscale, hipStream_t s);
+hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
+                         hipStream_t s);   // channels [C_valid, C) are written as zeros
 hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
@@ -135,8 +137,9 @@ struct GnApplyArgs {
     const float* res = nullptr; int ldr = 0;
     float* out = nullptr;
     float* stats_out = nullptr;       // [B*T][C/64][2] LayerNorm partial moments of the output rows (C % 64 == 0)
-    _Float16* out16 = nullptr;        // optional P16 copy of the output rows (C % 32 == 0), row stride ld16 halves
+    _Float16* out16 = nullptr;        // optional P16 copy of the output rows (C % 32 == 0), row stride ld16 halves; out may then be null
     int ld16 = 0;
+    const float* out16_mask = nullptr;// [B*T] multiplies the out16 copy only
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

@@ -379,10 +379,32 @@ struct DecBufs {
     float *Y = nullptr, *Hh = nullptr, *Rr = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
     float *mean = nullptr, *rstd = nullptr, *gnp = nullptr, *lnp = nullptr;
     _Float16* X16 = nullptr;             // P16 image of the residual stream x (the LayerNorm'd projections' LDS-DMA source)
+    // P16 decoder (decoder_eval_p16): every conv / projection input exists as a P16 image, written by its producer
+    bool p16 = false;
+    std::vector<_Float16*> A16, B16, S16;   // twins of bufA / bufB / skip per level (masked rows)
+    _Float16 *H16 = nullptr, *XM16 = nullptr;   // Block1D output (conv2 / final projection input); masked x|mu|0 state
     float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
     float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
     int ldx = 0, ldv = 0;
 };
+
+// Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
+// fp16-split mode and the shapes allow whole 32-channel groups and 64-wide heads; MTTS_P16=0 keeps the fp32-operand path.
+static bool p16_blocks(const mtts_ctx* c, int C) {
+    static const bool env_on = [] { const char* e = getenv("MTTS_P16"); return !(e && e[0] == '0'); }();
+    const mtts_config& g = c->cfg;
+    return env_on && c->gemm_terms == 2 && (C % 64) == 0 && g.dec_head_dim == 64;
+}
+
+// The whole estimator runs on P16 images (decoder_eval_p16) when every level qualifies and there is at least one transformer
+// block per ResNet (the ResNet output then always feeds a LayerNorm'd projection first).
+static bool p16_decoder(const mtts_ctx* c) {
+    const mtts_config& g = c->cfg;
+    if (g.dec_n_blocks < 1 || (g.n_feats & 1)) return false;
+    for (int l = 0; l < g.dec_levels; ++l)
+        if (!p16_blocks(c, g.dec_channels[l])) return false;
+    return true;
+}
 
 static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_state, int n_vel, WS& ws, DecBufs& d) {
     const mtts_config& g = c->cfg;
@@ -407,6 +429,18 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     d.mean = ws.f(M0); d.rstd = ws.f(M0);
     d.lnp = ws.f(M0 * (size_t)((cmax + 63) / 64) * 2);
     d.X16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(cmax, 32)));
+    d.p16 = p16_decoder(c);
+    if (d.p16) {
+        d.A16.resize(d.nl); d.B16.resize(d.nl); d.S16.resize(d.nl);
+        for (int l = 0; l < d.nl; ++l) {
+            const size_t Ml = (size_t)B * d.Tl[l];
+            d.A16[l] = reinterpret_cast<_Float16*>(ws.f(Ml * cmax));
+            d.B16[l] = reinterpret_cast<_Float16*>(ws.f(Ml * cmax));
+            d.S16[l] = reinterpret_cast<_Float16*>(ws.f(Ml * cmax));
+        }
+        d.H16 = reinterpret_cast<_Float16*>(ws.f(M0 * cmax));
+        d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, GEMM_BK)));
+    }
     d.gnp = ws.f((size_t)B * gn_chunks(T) * 8 * 2);
     d.ldx = round_up(2 * g.n_feats, GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
@@ -441,14 +475,6 @@ static int time_embed(mtts_ctx* c, DecBufs& d, const TimeVals& tv, int nt, hipSt
     m.a0 = d.T3; m.lda0 = temb; m.c0 = temb; m.out = d.TB; m.ldc = D.tb_total;
     RET_IF(run_gemm(c, m, s));
     return 0;
-}
-
-// Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
-// fp16-split mode and the shapes allow whole 32-channel groups and 64-wide heads; MTTS_P16=0 keeps the fp32-operand path.
-static bool p16_blocks(const mtts_ctx* c, int C) {
-    static const bool env_on = [] { const char* e = getenv("MTTS_P16"); return !(e && e[0] == '0'); }();
-    const mtts_config& g = c->cfg;
-    return env_on && c->gemm_terms == 2 && (C % 64) == 0 && g.dec_head_dim == 64;
 }
 
 // ResnetBlock1D.forward (reference decoder.py:58-63) on channels-last rows; input = up to two channel segments.
@@ -492,8 +518,9 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
 // leaves per-row partial moments of its 64-column slices behind (stats_out) and the next projection merges them in its
 // prologue; the ResNet block's last kernel (gn_apply) does the same for the first LayerNorm after it.  The row_stats
 // kernel only runs for widths that are not a multiple of 64 (the tiny test model).
+// last16 / last16_mask (P16 decoder): where the LAST block of a run leaves the masked P16 image of x for the convs.
 static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x, int C, int lvl, bool have_stats, bool emit_stats,
-                             hipStream_t s) {
+                             hipStream_t s, _Float16* last16 = nullptr) {
     const mtts_config& g = c->cfg;
     const int B = d.B, T = d.Tl[lvl], M = B * T, inner = g.dec_heads * g.dec_head_dim;
     const bool fuse = (C % 64) == 0;
@@ -527,6 +554,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
         f2.a16_0 = FF16; f2.lda16_0 = 8 * C; f2.c0 = 4 * C; f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C;
         if (emit_stats) { f2.stats_out = d.lnp; f2.out16 = d.X16; f2.ld16 = 2 * C; }
+        else if (last16) { f2.out16 = last16; f2.ld16 = 2 * C; f2.out16_mask = d.mask[lvl]; }
         RET_IF(run_gemm(c, f2, s));
         return 0;
     }
@@ -572,7 +600,9 @@ struct FinalOut {   // where the masked velocity goes: out = v * scale (+ res)
 
 // Decoder.forward (reference decoder.py:359-426) for evaluation `ev` (row of the precomputed time biases).
 // xin: channels-last state [B*T, ldx] holding x | mu.
+static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s);
 static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s) {
+    if (d.p16) return decoder_eval_p16(c, d, xin, ev, fo, s);
     const mtts_config& g = c->cfg;
     const DecW& D = c->dec;
     const int nl = d.nl, nb = g.dec_n_blocks, B = d.B;
@@ -656,6 +686,135 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     GemmArgs p;
     panel_args(c, D.final_proj, p); rows_plain(p, B, T);
     p.a0 = d.Hh; p.lda0 = C0; p.c0 = C0; p.out_mask = d.mask[0];
+    p.out = fo.out; p.ldc = fo.ldc; p.res = fo.res; p.ldr = fo.ldr; p.out_scale = fo.scale;
+    RET_IF(run_gemm(c, p, s));
+    return 0;
+}
+
+// ---- P16 decoder: the same network with every GEMM on pre-split operands (gemm_p16.hip).  Each producer writes the P16
+// image its consumers read (already multiplied by the frame mask where the reference masks the input): GroupNorm-apply,
+// the GEMM epilogues, and one conversion pass for the ODE state.  fp32 copies exist only where an fp32 consumer remains
+// (GroupNorm statistics of the conv outputs, the residual stream x, the ResNet skip sum).
+static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Float16* in0, int c0, const _Float16* in1, int c1,
+                            int lvl, const float* tbias, float* out, hipStream_t s) {
+    const int B = d.B, T = d.Tl[lvl], C = r.cout;
+    const float* mask = d.mask[lvl];
+    GemmArgs a;
+    panel_args(c, r.conv1, a); rows_plain(a, B, T); taps_centered(a, 3);
+    a.a16_0 = in0; a.lda16_0 = 2 * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = 2 * c1; a.c1 = c1;
+    a.out = d.Y; a.ldc = C;
+    RET_IF(run_gemm(c, a, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    GnApplyArgs g1;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask;
+    g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
+    LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
+    GemmArgs b;
+    panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
+    b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
+    RET_IF(run_gemm(c, b, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    GemmArgs rc;
+    panel_args(c, r.res, rc); rows_plain(rc, B, T);
+    rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
+    rc.out = d.Rr; rc.ldc = C;
+    RET_IF(run_gemm(c, rc, s));
+    GnApplyArgs g2;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask;
+    g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
+    g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
+    LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
+    return 0;
+}
+
+static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s) {
+    const mtts_config& g = c->cfg;
+    const DecW& D = c->dec;
+    const int nl = d.nl, nb = g.dec_n_blocks, B = d.B;
+    const float* tb = d.TB + (size_t)ev * D.tb_total;
+    size_t ri = 0, ti = 0;
+    // masked x | mu | zero padding as a P16 image (reference decoder.py:379: the first ResNet sees x * mask)
+    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, 2 * d.ldx, 2048.0f, s));
+    const _Float16* cur = d.XM16;
+    int cur_c = d.ldx;
+    // ---- down path
+    for (int l = 0; l < nl; ++l) {
+        const ResnetW& r = D.res[ri++];
+        if (r.conv1.ktap != cur_c) { set_error("P16 decoder: unexpected ResNet input width"); return -1; }
+        RET_IF(resnet_block_p16(c, d, r, cur, cur_c, nullptr, 0, l, tb + r.tb_off, d.skip[l], s));
+        for (int j = 0; j < nb; ++j)
+            RET_IF(transformer_block(c, d, D.tb[ti++], d.skip[l], r.cout, l, true, j + 1 < nb, s, d.S16[l]));
+        GemmArgs a;
+        panel_args(c, D.down[l], a);
+        taps_centered(a, 3);
+        a.a16_0 = d.S16[l]; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+        a.B = B; a.T_in = d.Tl[l];
+        const int lo = l < nl - 1 ? l + 1 : l;
+        if (l < nl - 1) { a.T_out = d.Tl[l + 1]; a.in_stride = 2; a.out_T = d.Tl[l + 1]; }   // Downsample1D (reference decoder.py:66-72)
+        else { a.T_out = d.Tl[l]; a.out_T = d.Tl[l]; }                                          // last level: Conv1d(k3, p1)
+        a.out16 = d.A16[lo]; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[lo];
+        RET_IF(run_gemm(c, a, s));
+        cur = d.A16[lo]; cur_c = r.cout;
+    }
+    // ---- mid blocks at the coarsest level
+    const int lm = nl - 1;
+    float* xbuf = d.bufA[lm];
+    _Float16* x16 = d.B16[lm];
+    for (int i = 0; i < g.dec_mid_blocks; ++i) {
+        const ResnetW& r = D.res[ri++];
+        RET_IF(resnet_block_p16(c, d, r, cur, cur_c, nullptr, 0, lm, tb + r.tb_off, xbuf, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], xbuf, r.cout, lm, true, j + 1 < nb, s, x16));
+        cur = x16; cur_c = r.cout;
+        x16 = (x16 == d.B16[lm]) ? d.A16[lm] : d.B16[lm];
+    }
+    // ---- up path
+    for (int i = 0; i < nl; ++i) {
+        const int l = nl - 1 - i;
+        const ResnetW& r = D.res[ri++];
+        const int cskip = g.dec_channels[l];
+        float* xb = d.bufA[l];
+        _Float16* dst16 = (cur == d.B16[l]) ? d.A16[l] : d.B16[l];
+        RET_IF(resnet_block_p16(c, d, r, cur, cur_c, d.S16[l], cskip, l, tb + r.tb_off, xb, s));
+        for (int j = 0; j < nb; ++j) RET_IF(transformer_block(c, d, D.tb[ti++], xb, r.cout, l, true, j + 1 < nb, s, dst16));
+        if (i < nl - 1) {   // Upsample1D: ConvTranspose1d(k4, s2, p1) as two phase GEMMs (reference decoder.py:146)
+            _Float16* up16 = d.A16[l - 1];
+            for (int ph = 0; ph < 2; ++ph) {
+                GemmArgs a;
+                panel_args(c, ph == 0 ? D.up_even[i] : D.up_odd[i], a);
+                a.a16_0 = dst16; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+                a.B = B; a.T_in = d.Tl[l]; a.T_out = d.Tl[l]; a.in_stride = 1;
+                a.tap_off[0] = ph == 0 ? 0 : 1;
+                a.tap_off[1] = ph == 0 ? -1 : 0;
+                a.out16 = up16; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[l - 1];
+                a.out_T = d.Tl[l - 1]; a.out_stride = 2; a.out_off = ph;
+                RET_IF(run_gemm(c, a, s));
+            }
+            cur = up16;
+        } else {
+            GemmArgs a;
+            panel_args(c, D.up_last, a); rows_plain(a, B, d.Tl[l]); taps_centered(a, 3);
+            a.a16_0 = dst16; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+            _Float16* o16 = (dst16 == d.A16[l]) ? d.B16[l] : d.A16[l];
+            a.out16 = o16; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[l];
+            RET_IF(run_gemm(c, a, s));
+            cur = o16;
+        }
+        cur_c = r.cout;
+    }
+    // ---- final Block1D + 1x1 projection + mask (reference decoder.py:423-426)
+    const int C0 = g.dec_channels[0], T = d.T;
+    GemmArgs a;
+    panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
+    a.a16_0 = cur; a.lda16_0 = 2 * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
+    RET_IF(run_gemm(c, a, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s));
+    GnApplyArgs ga;
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0];
+    ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
+    LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
+    GemmArgs p;
+    panel_args(c, D.final_proj, p); rows_plain(p, B, T);
+    p.a16_0 = d.H16; p.lda16_0 = 2 * C0; p.c0 = C0; p.out_mask = d.mask[0];
     p.out = fo.out; p.ldc = fo.ldc; p.res = fo.res; p.ldr = fo.ldr; p.out_scale = fo.scale;
     RET_IF(run_gemm(c, p, s));
     return 0;
@@ -1048,7 +1207,7 @@ int mtts_gemm_p16(const float* d_a, int lda, int B, int T_in, int C, int ntaps, 
     _Float16* o16 = reinterpret_cast<_Float16*>(sc);
     sc += (size_t)B * T_out * round_up(N, 32) * 4;
     float* wsum = reinterpret_cast<float*>(sc);
-    HIP_OK(launch_to_p16(d_a, lda, d_a_mask, B * T_in, C, a16, 2 * C, 2048.0f, s));
+    HIP_OK(launch_to_p16(d_a, lda, d_a_mask, B * T_in, C, C, a16, 2 * C, 2048.0f, s));
     hipLaunchKernelGGL(panel_rowsum_kernel, dim3((Np + 127) / 128), dim3(128), 0, s, static_cast<const float*>(d_wpacked), Np, Kp, wsum);
     HIP_OK(hipGetLastError());
     GemmArgs a;
@@ -1083,7 +1242,7 @@ int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, in
     const int M = B * T, C3 = 3 * H * D;
     _Float16* q16 = static_cast<_Float16*>(d_scratch);
     _Float16* o16 = q16 + (size_t)M * 2 * C3;
-    HIP_OK(launch_to_p16(d_qkv, C3, nullptr, M, C3, q16, 2 * C3, 1.0f, s));
+    HIP_OK(launch_to_p16(d_qkv, C3, nullptr, M, C3, C3, q16, 2 * C3, 1.0f, s));
     AttnArgs a;
     a.qkv16 = q16; a.ld16 = 2 * C3; a.out16 = o16; a.ldo16 = 2 * H * D; a.mask = d_mask;
     a.B = B; a.T = T; a.H = H; a.D = D; a.scale = scale; a.mask_mode = mask_mode;

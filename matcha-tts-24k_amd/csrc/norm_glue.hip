@@ -229,14 +229,16 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
         for (int e = 0; e < 4; ++e) o[e] = mish_f(o[e]) * mk;
         if (p.chbias) o = (o + cb) * mk;
         if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + c4 * 4);
-        *reinterpret_cast<f32x4*>(p.out + row * p.C + c4 * 4) = o;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.C + c4 * 4) = o;
         if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
             using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
             f16x4 hh, ll;
+            const float m16 = p.out16_mask ? p.out16_mask[row] : 1.0f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hh[e] = (_Float16)fminf(fmaxf(o[e], -65504.f), 65504.f);
-                ll[e] = (_Float16)fminf(fmaxf((o[e] - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
+                const float v = o[e] * m16;
+                hh[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+                ll[e] = (_Float16)fminf(fmaxf((v - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
             }
             _Float16* o16 = p.out16 + row * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
             *reinterpret_cast<f16x4*>(o16) = hh;
@@ -257,7 +259,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
 }
 
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
-    if (!a.y || !a.partial || !a.gamma || !a.beta || !a.mask || !a.out || a.B <= 0 || a.T <= 0 || !gn_shape_ok(a.C, a.G) ||
+    if (!a.y || !a.partial || !a.gamma || !a.beta || !a.mask || (!a.out && !a.out16) || a.B <= 0 || a.T <= 0 || !gn_shape_ok(a.C, a.G) ||
         (a.res && (a.ldr & 3)))
         return hipErrorInvalidValue;
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
