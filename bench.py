@@ -197,7 +197,7 @@ def main():
         _, instr, products, hw_peak = GEMM_MODES[terms]
         peak = hw_peak / products      # fp32-equivalent peak: every algorithmic MAC costs `products` MFMA MACs
         roofline = {
-            "bound": "mfma", "kernel": "gemm_f32_kernel (GEMM / implicit conv1d, all instantiations)",
+            "bound": "mfma", "kernel": "gemm_p16_kernel + gemm_f32_kernel (GEMM / implicit conv1d, all instantiations)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
             "peak_basis": f"{hw_peak:.0f} TFLOP/s dense ({instr}) / {products}",

@@ -76,7 +76,8 @@ struct mtts_ctx {
     std::vector<float> image;     // host staging of the packed device image
     float* d_image = nullptr;     // caller-owned device buffer
     bool packed = false, uploaded = false;
-    int gemm_terms = 6;           // 0: fp32 MFMA, 6 / 3: split-bf16 MFMA (MTTS_GEMM_TERMS; see gemm_f32.hip)
+    int gemm_terms = 6;           // 0: fp32 MFMA, 6 / 3: split-bf16 MFMA, 2: split-fp16 (MTTS_GEMM_TERMS; see gemm_f32.hip)
+    bool p16_on = true;           // fp16-split mode: activations as P16 images between kernels (MTTS_P16=0 at mtts_create disables)
     mtts::DecW dec;
     mtts::EncW enc;
     // profiling

@@ -389,11 +389,11 @@ struct DecBufs {
 };
 
 // Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
-// fp16-split mode and the shapes allow whole 32-channel groups and 64-wide heads; MTTS_P16=0 keeps the fp32-operand path.
+// fp16-split mode and the shapes allow whole 32-channel groups and 64-wide heads; MTTS_P16=0 (read at mtts_create) keeps
+// the fp32-operand path.
 static bool p16_blocks(const mtts_ctx* c, int C) {
-    static const bool env_on = [] { const char* e = getenv("MTTS_P16"); return !(e && e[0] == '0'); }();
     const mtts_config& g = c->cfg;
-    return env_on && c->gemm_terms == 2 && (C % 64) == 0 && g.dec_head_dim == 64;
+    return c->p16_on && c->gemm_terms == 2 && (C % 64) == 0 && g.dec_head_dim == 64;
 }
 
 // The whole estimator runs on P16 images (decoder_eval_p16) when every level qualifies and there is at least one transformer
@@ -859,6 +859,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     mtts_ctx* c = new mtts_ctx();
     c->cfg = g;
     c->gemm_terms = default_gemm_terms();
+    { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
     return c;
 }
 

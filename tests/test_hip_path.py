@@ -200,6 +200,24 @@ def test_prod_single_utterance_vs_golden(prod, synthetic, dev):
     assert maxabs(out4["mel"], _t(g["mel_midpoint4"])) < MEL_TOL
 
 
+def test_prod_fp32_operand_path_vs_golden(prod, synthetic, dev, monkeypatch):
+    """MTTS_P16=0 (read when the context is created) keeps activations in fp32 between kernels (gemm_f32.hip splits them in
+    its loop): same golden, and within rounding of the default P16 flow."""
+    hp, sd, model = prod
+    g = np.load(GOLDEN / "prod_synth.npz")
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
+    z = synthetic.cpu_noise((1, 100, 640)).to(dev)
+    monkeypatch.setenv("MTTS_P16", "0")
+    plain = make_model(hp, sd, dev)
+    plain.decoder.solver = "euler"
+    out = plain.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    monkeypatch.delenv("MTTS_P16")
+    assert maxabs(out["mel"], _t(g["mel_euler2"])) < MEL_TOL
+    model.decoder.solver = "euler"
+    ref = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    assert maxabs(out["mel"], ref["mel"]) < 2e-4
+
+
 def test_prod_ragged_batch_vs_golden(hparams, synthetic, dev):
     hp = hparams.prod_v20(n_spks=3)
     sd = synthetic.make_state_dict(hp, seed=7)

@@ -15,6 +15,9 @@
 #ifndef ILV
 #define ILV 0   // 1: operands stored [rows][K/32][h 32 | l 32] so every row piece is a full 128-B line
 #endif
+#ifndef BIG
+#define BIG 0
+#endif
 #ifndef MINB
 #define MINB 2
 #endif
@@ -179,6 +182,103 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes(const h16* __restrict__
     }
 }
 
+
+// ---- BIG: 256 x 128 tile, 8 waves (4 x 2, wave tile 64 x 64), 3-stage LDS ring with TWO tiles in flight across the
+// barrier (counted vmcnt, raw s_barrier), one workgroup per CU.  ILV layout only.
+constexpr int BIG_STAGE = (256 + 128) * 128;        // 48 KiB
+constexpr int BIG_LDS = 3 * BIG_STAGE;              // 144 KiB (the epilogue's 8 x 64 x 68 floats = 136 KiB fit inside)
+__global__ __launch_bounds__(512, 1) void gemm_planes_big(const h16* __restrict__ A, const h16* __restrict__ W,
+                                                          float* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntm = (M + 255) / 256, ntn = N / 128, nwg = ntm * ntn;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tm = wg / ntn, tn = wg - tm * ntn;
+    const int row0 = tm * 256, col0 = tn * 128;
+    const h16* srcA[4]; const h16* srcW[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j, rr = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+        srcA[j] = A + (size_t)min(row0 + rr, M - 1) * K * 2 + chunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wave * 2 + j, rr = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+        srcW[j] = W + (size_t)(col0 + rr) * K * 2 + chunk * 8;
+    }
+    auto issue = [&](int st) {
+        char* base = lds + st * BIG_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { GLDS16(srcA[j], base + (wave * 4 + j) * 1024); srcA[j] += 64; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { GLDS16(srcW[j], base + 256 * 128 + (wave * 2 + j) * 1024); srcW[j] += 64; }
+    };
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+    const int fr = lane & 31, fh = lane >> 5, f8 = (fr >> 1) & 7;
+    const int nk = K / BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed for this wave once at most the 6 DMAs of tile kt+1 are outstanding; lgkmcnt(0): this wave's
+        // reads of tile kt-1 are complete, so after the barrier its stage may be refilled
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nk) issue(st >= 1 ? st - 1 : 2);      // stage (kt+2) % 3 == (st + 2) % 3
+        const char* sb = lds + st * BIG_STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            h16x8 ah[2], al[2], bh[2], bl[2];
+            const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ro = (wm * 64 + i * 32 + fr) * 128;
+                ah[i] = *reinterpret_cast<const h16x8*>(sb + ro + sh);
+                al[i] = *reinterpret_cast<const h16x8*>(sb + ro + sl);
+                const int co = 256 * 128 + (wn * 64 + i * 32 + fr) * 128;
+                bh[i] = *reinterpret_cast<const h16x8*>(sb + co + sh);
+                bl[i] = *reinterpret_cast<const h16x8*>(sb + co + sl);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    __syncthreads();
+    float* et = reinterpret_cast<float*>(lds) + wave * 64 * 68;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, cc = j * 32 + fr;
+                et[rr * 68 + cc] = acc[i][j][e] + accx[i][j][e] * (1.0f / 2048.0f);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        const int grow = row0 + wm * 64 + rr;
+        if (grow < M) *reinterpret_cast<f32x4*>(C + (size_t)grow * N + col0 + wn * 64 + cc) = *reinterpret_cast<const f32x4*>(et + rr * 68 + cc);
+    }
+}
+
 int main(int argc, char** argv) {
     int M = argc > 1 ? atoi(argv[1]) : 20480, N = argc > 2 ? atoi(argv[2]) : 1152, K = argc > 3 ? atoi(argv[3]) : 384;
     int iters = argc > 4 ? atoi(argv[4]) : 50;
@@ -199,9 +299,15 @@ int main(int argc, char** argv) {
     split_kernel<<<1024, 256>>>(dA, pA, pA + hA.size(), hA.size());
     split_kernel<<<1024, 256>>>(dW, pW, pW + hW.size(), hW.size());
 #endif
+#if BIG
+    const int grid = ((M + 255) / 256) * (N / BN);
+    hipFuncSetAttribute((const void*)gemm_planes_big, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    auto run = [&]() { gemm_planes_big<<<grid, 512, BIG_LDS>>>(pA, pW, dC, M, N, K); };
+#else
     const int grid = ((M + BM - 1) / BM) * (N / BN);
     hipFuncSetAttribute((const void*)gemm_planes, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     auto run = [&]() { gemm_planes<<<grid, 256, LDS_BYTES>>>(pA, pA + hA.size(), pW, pW + hW.size(), dC, M, N, K); };
+#endif
     run();
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
     std::vector<float> hC((size_t)M * N);
@@ -221,7 +327,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("planes ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", ILV, NBUF, MINB, M, N, K, grid,
+    printf("planes BIG=%d ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", BIG, ILV, NBUF, MINB, M, N, K, grid,
            LDS_BYTES, us, tf, maxerr, maxref);
     return 0;
 }
