@@ -152,14 +152,21 @@ def _plain(obj):
 
 
 def load_matcha(model_name, checkpoint_path):
-    """reference inference.py:186-197: Lightning checkpoint with ``hyper_parameters`` + ``state_dict``."""
+    """reference inference.py:186-197: Lightning checkpoint with ``hyper_parameters`` + ``state_dict``; also accepts a
+    directory written by ``checkpoint.convert_lightning_checkpoint`` (flat safetensors + JSON, no lightning / omegaconf)."""
     print(f"[!] Loading {model_name}!")
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
-    hparams = dict(_plain(ckpt["hyper_parameters"]))
-    hparams.pop("optimizer", None)
-    hparams.pop("scheduler", None)
-    model = MatchaTTSInfer(**hparams)
-    model.load_state_dict(ckpt["state_dict"], strict=False)
+    from . import checkpoint as ck
+    if ck.is_converted(checkpoint_path):
+        hp, sd = ck.load_converted(checkpoint_path)
+        model = MatchaTTSInfer(**hp.as_reference_kwargs())
+        model.load_state_dict(sd, strict=True)
+    else:
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hparams = dict(_plain(ckpt["hyper_parameters"]))
+        hparams.pop("optimizer", None)
+        hparams.pop("scheduler", None)
+        model = MatchaTTSInfer(**hparams)
+        model.load_state_dict(ckpt["state_dict"], strict=False)
     model = model.to(DEVICE).eval()
     print(f"[+] {model_name} loaded!")
     return model
