@@ -104,6 +104,15 @@ int mtts_durations(const float* d_logw, const float* d_x_mask, float scale_corre
 int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_y_fine_lengths, int B, int n_feats,
                     int Tx, int T_pad, float* d_mu_y, float* d_y_mask, int64_t* d_y_lengths, void* stream);
 
+/* Per-request padding inside a batch.  The reference computes T_pad, the GroupNorm statistics, the attention key set and
+ * the noise shape from the longest utterance of the call (inference.py:147-148, decoder.py:32-45, transformer.py:249-261),
+ * so an utterance's mel depends on what it was batched with.  With d_t_len[b] (device int32, even, <= T) set, the next
+ * mtts_decoder_forward / mtts_cfm_solve calls treat utterance b as if only frames [0, d_t_len[b]) existed: GroupNorm
+ * statistics and attention keys stop there (convolutions already read masked zeros beyond it), so every utterance of a
+ * ragged batch gets exactly the values of a batch-of-one call.  NULL restores whole-batch padding.  The pointer is kept,
+ * not copied: it must stay valid until replaced. */
+int mtts_set_frame_limits(mtts_ctx* ctx, const int32_t* d_t_len);
+
 /* Decoder.forward -- reference matcha/models/components/decoder.py:359-426 (one evaluation of the velocity field).
  * d_x, d_mu, d_out [B,n_feats,T]; d_mask [B,1,T]; t scalar. */
 int64_t mtts_decoder_workspace_bytes(mtts_ctx* ctx, int B, int T);

@@ -81,6 +81,7 @@ def load() -> C.CDLL:
         "mtts_speaker_embedding": (i32, [vp, i32, vp, i32, vp, vp]),
         "mtts_durations": (i32, [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp]),
         "mtts_align_pool": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "mtts_set_frame_limits": (i32, [vp, vp]),
         "mtts_decoder_workspace_bytes": (i64, [vp, i32, i32]),
         "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
@@ -280,6 +281,14 @@ class HipModel:
         check(self.lib.mtts_align_pool(ptr(mu_x), ptr(cum), ptr(y_fine_lengths), B, nf, Tx, t_pad, ptr(mu_y), ptr(y_mask),
                                        ptr(y_len), stream_ptr()))
         return mu_y, y_mask, y_len
+
+    def set_frame_limits(self, t_len: Optional[torch.Tensor]) -> None:
+        """Per-utterance frame limits (int32 [B] on the device, even) for the following estimator calls; None clears."""
+        if t_len is not None:
+            if t_len.dtype != torch.int32 or not t_len.is_cuda or not t_len.is_contiguous():
+                raise RuntimeError("mtts: frame limits must be a contiguous int32 tensor on the HIP device")
+        self._t_len = t_len                     # keep it alive: the library stores the pointer
+        check(self.lib.mtts_set_frame_limits(self.ctx, None if t_len is None else t_len.data_ptr()))
 
     def decoder_forward(self, x, mask, mu, t: float):
         x, mask, mu = self._f32(x), self._f32(mask), self._f32(mu)

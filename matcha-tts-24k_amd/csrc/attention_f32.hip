@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     const int q0 = qb * (NW * AT_QW) + wave * AT_QW;
     const int ld = 3 * p.H * p.D;
     const size_t rowbase = (size_t)b * p.T;
+    const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;      // keys of this utterance: [0, Tb) (per-request padding)
     const float* qptr = p.qkv + head * p.D;
     const float* kptr = p.qkv + p.H * p.D + head * p.D;
     const float* vptr = p.qkv + 2 * p.H * p.D + head * p.D;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
         for (int sp = 0; sp < SP; ++sp) {
             const int key = k0 + srow + SROWS * sp;
-            r_in[sp] = key < p.T;
+            r_in[sp] = key < Tb;
             const size_t row = rowbase + (r_in[sp] ? key : 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         }
     };
 
-    const int ntiles = (p.T + AT_K - 1) / AT_K;
+    const int ntiles = (Tb + AT_K - 1) / AT_K;
     fetch(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         if (kt) __syncthreads();          // everyone finished reading the previous tile

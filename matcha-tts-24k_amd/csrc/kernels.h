@@ -103,6 +103,8 @@ struct AttnArgs {
     const _Float16* qkv16 = nullptr; int ld16 = 0;     // row stride in halves (>= 6*H*64)
     _Float16* out16 = nullptr; int ldo16 = 0;          // row stride in halves (>= 2*H*64)
     float out_lscale = 2048.0f;
+    const int* tlen = nullptr;    // [B] per-utterance frame limit (>> tshift): keys at or beyond it do not exist; null = T
+    int tshift = 0;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
@@ -127,7 +129,9 @@ hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
 // GroupNorm statistics over (C/G channels x T frames) of y [B,T,C]: partial (mean, M2) per chunk of GN_CHUNK rows.
 constexpr int GN_CHUNK = 32;
 static inline int gn_chunks(int T) { return (T + GN_CHUNK - 1) / GN_CHUNK; }
-hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s);
+// tlen (optional, [B] int32): utterance b only has frames [0, tlen[b] >> tshift); statistics ignore the rest
+hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* tlen = nullptr,
+                             int tshift = 0);
 // out = Mish(GN(y)) ; out = (out [+ chbias[c]]) * mask[row] ; out += res[row][c]
 struct GnApplyArgs {
     const float* y = nullptr; const float* partial = nullptr;
@@ -140,6 +144,8 @@ struct GnApplyArgs {
     _Float16* out16 = nullptr;        // optional P16 copy of the output rows (C % 32 == 0), row stride ld16 halves; out may then be null
     int ld16 = 0;
     const float* out16_mask = nullptr;// [B*T] multiplies the out16 copy only
+    const int* tlen = nullptr;        // [B] per-utterance frame limit (>> tshift) for the statistics; null = T
+    int tshift = 0;
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

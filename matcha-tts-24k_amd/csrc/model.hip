@@ -487,23 +487,23 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
     a.a0 = in0; a.lda0 = ld0; a.c0 = c0; a.a1 = in1; a.lda1 = ld1; a.c1 = c1; a.a_mask = mask;
     a.out = d.Y; a.ldc = C;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GnApplyArgs g1;
-    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.tlen = c->d_tlen; g1.tshift = lvl;
     g1.chbias = tbias; g1.out = d.Hh; g1.B = B; g1.T = T; g1.C = C;
     LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a0 = d.Hh; b.lda0 = C; b.c0 = C; b.out = d.Y; b.ldc = C;      // Hh is already masked
     RET_IF(run_gemm(c, b, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a0 = in0; rc.lda0 = ld0; rc.c0 = c0; rc.a1 = in1; rc.lda1 = ld1; rc.c1 = c1; rc.a_mask = mask;
     rc.out = d.Rr; rc.ldc = C;
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
-    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
     g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
     if (emit_stats && (C % 64) == 0) {       // for the first transformer block: LayerNorm moments and, in P16 mode, x's image
         g2.stats_out = d.lnp;
@@ -538,7 +538,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         AttnArgs at;
         at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.mask[lvl];
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0;
+        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl;
         RET_IF(run_attn(c, at, s));
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -569,7 +569,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
     RET_IF(run_gemm(c, q, s));
     AttnArgs at;
     at.qkv = d.QKV; at.mask = d.mask[lvl]; at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0;
+    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl;
     RET_IF(run_attn(c, at, s));
     GemmArgs o;
     panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -678,9 +678,9 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a0 = cur; a.lda0 = cur_ld; a.c0 = C0; a.a_mask = d.mask[0]; a.out = d.Y; a.ldc = C0;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
     GnApplyArgs ga;
-    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0];
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.tlen = c->d_tlen;
     ga.out = d.Hh; ga.B = B; ga.T = T; ga.C = C0;
     LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
     GemmArgs p;
@@ -704,23 +704,23 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     a.a16_0 = in0; a.lda16_0 = 2 * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = 2 * c1; a.c1 = c1;
     a.out = d.Y; a.ldc = C;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GnApplyArgs g1;
-    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.tlen = c->d_tlen; g1.tshift = lvl;
     g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
     LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
     RET_IF(run_gemm(c, b, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
     rc.out = d.Rr; rc.ldc = C;
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
-    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
     g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
     g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
     LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
@@ -807,9 +807,9 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a16_0 = cur; a.lda16_0 = 2 * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
     GnApplyArgs ga;
-    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0];
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.tlen = c->d_tlen;
     ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
     LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
     GemmArgs p;
@@ -900,6 +900,12 @@ int64_t mtts_decoder_workspace_bytes(mtts_ctx* c, int B, int T) {
     DecBufs d;
     if (plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d)) return -1;
     return (int64_t)ws.off + 256;
+}
+
+int mtts_set_frame_limits(mtts_ctx* c, const int32_t* d_t_len) {
+    if (!c) { set_error("null context"); return -1; }
+    c->d_tlen = d_t_len;
+    return 0;
 }
 
 int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, const float* d_mu, float t, int B, int T,

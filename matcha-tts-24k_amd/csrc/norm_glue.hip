@@ -122,16 +122,26 @@ hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
 // Pass 1: per chunk of GN_CHUNK rows, (mean, M2) about the chunk mean.  Pass 2 merges the chunk moments in chunk order
 // (Chan et al.) and applies GN affine -> Mish -> mask [-> + time bias -> mask] [-> + residual].
 // Block shape: x = C/4 float4 columns, y = RT row lanes.
-__global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int G, float* __restrict__ partial) {
+__global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int G, float* __restrict__ partial,
+                                  const int* __restrict__ tlen, int tshift) {
     extern __shared__ float red[];                 // [blockDim.x*blockDim.y] + [G]
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int c4 = threadIdx.x, ry = threadIdx.y, RT = blockDim.y, nth = blockDim.x * blockDim.y;
     const int tid = ry * blockDim.x + c4;
     const int t0 = chunk * GN_CHUNK;
-    const int rows = min(GN_CHUNK, T - t0);
+    const int Tb = tlen ? min(T, tlen[b] >> tshift) : T;       // this utterance's own length (per-request padding)
+    const int rows = max(0, min(GN_CHUNK, Tb - t0));
     const int cpg4 = (C / G) / 4;                  // float4 columns per group
     const float* base = y + ((size_t)b * T + t0) * C + c4 * 4;
     float* gmean = red + nth;
+    if (rows == 0) {                               // chunk beyond the utterance: an empty partial, skipped by the merge
+        if (tid < G) {
+            float* o = partial + (((size_t)b * nchunks + chunk) * G + tid) * 2;
+            o[0] = 0.f;
+            o[1] = 0.f;
+        }
+        return;
+    }
 
     float s = 0.f;
     for (int r = ry; r < rows; r += RT) {
@@ -174,11 +184,11 @@ static inline dim3 gn_block(int C) {
     return dim3(c4, rt);
 }
 
-hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s) {
+hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* tlen, int tshift) {
     if (!y || !partial || B <= 0 || T <= 0 || !gn_shape_ok(C, G)) return hipErrorInvalidValue;
     const dim3 blk = gn_block(C);
     const size_t lds = (size_t)(blk.x * blk.y + G) * sizeof(float);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(T), B), blk, lds, s, y, T, C, G, partial);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(T), B), blk, lds, s, y, T, C, G, partial, tlen, tshift);
     return hipGetLastError();
 }
 
@@ -199,9 +209,11 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
     const int cpg = p.C / p.G;
     if (tid < p.G) {
         float n = 0.f, mean = 0.f, m2 = 0.f;
+        const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;
         for (int k = 0; k < nchunks; ++k) {
+            if (Tb - k * GN_CHUNK <= 0) break;
             const float* q = p.partial + (((size_t)b * nchunks + k) * p.G + tid) * 2;
-            const float nb = (float)(min(GN_CHUNK, p.T - k * GN_CHUNK) * cpg);
+            const float nb = (float)(min(GN_CHUNK, Tb - k * GN_CHUNK) * cpg);
             const float delta = q[0] - mean;
             const float nt = n + nb;
             mean += delta * (nb / nt);

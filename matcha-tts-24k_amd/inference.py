@@ -100,13 +100,18 @@ class MatchaTTSInfer(nn.Module):
 
     @torch.inference_mode()
     def synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
-                   debug=False, z=None, sync_max=None):
+                   debug=False, z=None, sync_max=None, per_request_padding=False):
         """Text ids -> mel (reference inference.py:78-183).  Returns ``{"mel": [B, n_feats, T_valid_max]}`` (+ the
         reference's debug tensors when ``debug``).
 
         ``z``: explicit noise [B, n_feats, T_pad], or a callable ``T_pad -> noise``; default = the device seed-42
         generator like the reference.  ``sync_max``: callable mapping this process's maximum fine length to the
-        batch-wide one (data-parallel shards must pad like the whole batch, see dp.py)."""
+        batch-wide one (data-parallel shards must pad like the whole batch, see dp.py).
+        ``per_request_padding``: the reference derives the padded length, and with it the GroupNorm statistics, the
+        attention key set and the noise shape, from the longest utterance of the call, so a request's mel depends on what
+        it is batched with.  With this flag every utterance is padded (logically) to its OWN length: each row of a ragged
+        batch equals the batch-of-one result for that request (what a dynamic batcher in front of the reference's
+        one-request-at-a-time server needs); one extra host read of the B fine lengths."""
         hip = self._rt.ready()
         dev = x.device
         B = x.shape[0]
@@ -130,8 +135,13 @@ class MatchaTTSInfer(nn.Module):
         mu_y, y_mask, y_lengths = hip.align_pool(mu_x, cum, y_fine_lengths, t_pad)
         y_max_length = max((max_fine + 1) // 2, 1)
 
+        t_len = None
+        if per_request_padding:
+            if sync_max is not None:
+                raise ValueError("per_request_padding needs no batch-wide length: do not combine it with sync_max")
+            t_len = [fix_len_compatibility(max(int(v), 1)) for v in y_fine_lengths.tolist()]
         mel = self.decoder(mu_y, y_mask, n_timesteps, z=z, t_out=y_max_length, out_scale=self._rt.mel_std,
-                           out_shift=self._rt.mel_mean)
+                           out_shift=self._rt.mel_mean, t_len=t_len)
         if not debug:
             return {"mel": mel, "mel_lengths": y_lengths}
         encoder_mel = mu_y[:, :, :y_max_length] * self._rt.mel_std + self._rt.mel_mean

@@ -117,15 +117,32 @@ class CFM(nn.Module):
         g.manual_seed(42)
         return torch.randn(like.shape, generator=g, dtype=like.dtype, device=like.device)
 
+    def noise_per_request(self, like: torch.Tensor, t_len) -> torch.Tensor:
+        """Per-request padding: utterance b gets the seed-42 draw of shape [1, n_feats, t_len[b]] a batch-of-one call would
+        make (the draw depends on the shape), zero beyond it."""
+        z = torch.zeros_like(like)
+        for b, t in enumerate(t_len):
+            z[b:b + 1, :, :t] = self.noise(like[b:b + 1, :, :t])
+        return z
+
     @torch.inference_mode()
     def forward(self, mu, mask, n_timesteps, z: Optional[torch.Tensor] = None, t_out: Optional[int] = None,
-                out_scale: float = 1.0, out_shift: float = 0.0):
-        """``z``: optional explicit noise (e.g. the CPU-generator stream for parity with the CPU reference)."""
+                out_scale: float = 1.0, out_shift: float = 0.0, t_len=None):
+        """``z``: optional explicit noise (e.g. the CPU-generator stream for parity with the CPU reference).
+        ``t_len``: per-utterance padded lengths (list of even ints) for per-request padding (mtts_set_frame_limits)."""
+        hip = self._rt.ready()
         if z is None:
-            z = self.noise(mu)
+            z = self.noise(mu) if t_len is None else self.noise_per_request(mu, t_len)
         t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
-        return self._rt.ready().cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
-                                          out_scale=out_scale, out_shift=out_shift)
+        if t_len is None:
+            return hip.cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
+                                 out_scale=out_scale, out_shift=out_shift)
+        hip.set_frame_limits(torch.tensor(list(t_len), dtype=torch.int32, device=mu.device))
+        try:
+            return hip.cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
+                                 out_scale=out_scale, out_shift=out_shift)
+        finally:
+            hip.set_frame_limits(None)
 
     def solve(self, x, t_span, mu, mask):
         return self._rt.ready().cfm_solve(x, mu, mask, t_span, self.solver)

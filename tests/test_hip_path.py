@@ -231,6 +231,32 @@ def test_prod_ragged_batch_vs_golden(hparams, synthetic, dev):
     assert maxabs(out["mel"], _t(g["mel"])) < MEL_TOL
 
 
+@pytest.mark.parametrize("which,lengths,solver,steps", [("tiny", [12, 9, 5, 1], "midpoint", 2), ("prod", [128, 100, 77], "euler", 2)])
+def test_per_request_padding_equals_batch_of_one(which, lengths, solver, steps, tiny, hparams, synthetic, dev):
+    """per_request_padding: every utterance of a ragged batch gets the mel a batch-of-one call gives it (own padded length
+    for GroupNorm statistics, attention keys and the seed-42 noise shape), unlike the reference-faithful default, whose
+    result depends on the longest utterance in the call."""
+    if which == "tiny":
+        hp, sd, model = tiny
+    else:
+        hp = hparams.prod_v20(n_spks=3)
+        sd = synthetic.make_state_dict(hp, seed=7)
+        model = make_model(hp, sd, dev)
+    B = len(lengths)
+    x, x_len, spk = synthetic.make_inputs(hp, B, max(lengths), seed=99, lengths=lengths)
+    model.decoder.solver = solver
+    batched = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev), per_request_padding=True)
+    default = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev))
+    worst_default = 0.0
+    for b, n in enumerate(lengths):
+        alone = model.synthesise(x[b:b + 1, :n].to(dev), x_len[b:b + 1].to(dev), steps, speaker=spk[b:b + 1].to(dev))
+        t = int(alone["mel_lengths"][0])
+        assert int(batched["mel_lengths"][b]) == t
+        assert maxabs(batched["mel"][b, :, :t], alone["mel"][0, :, :t]) < 1e-5, f"utterance {b}"
+        worst_default = max(worst_default, maxabs(default["mel"][b, :, :t], alone["mel"][0, :, :t]))
+    assert worst_default > 1e-3        # the reference-faithful batch really does differ for the shorter utterances
+
+
 def test_config2_batch32_properties(prod, synthetic, dev):
     """BASELINE config #2 (B=32, Tx=128, euler/10) at full size: size-independent checks.
     All utterances of a batch are independent (per-sample norms and attention), so row b of the batched result must
