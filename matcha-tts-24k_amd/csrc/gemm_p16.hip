@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include "gemm_epilogue.h"
+#include <cstdlib>
 
 namespace mtts {
 
@@ -32,19 +33,23 @@ __device__ __attribute__((aligned(128))) _Float16 g_p16_zero_line[64];     // so
 constexpr int P16_CS = GEMM_CS;                                             // epilogue tile row stride (floats)
 constexpr int p16_stage_bytes(int BM) { return (BM + GEMM_BN) * 128; }
 constexpr int p16_epi_bytes(int BM) { return 4 * (BM / 2) * P16_CS * 4; }
-constexpr int p16_main_bytes(int BM) { return 2 * p16_stage_bytes(BM) > p16_epi_bytes(BM) ? 2 * p16_stage_bytes(BM) : p16_epi_bytes(BM); }
-constexpr int p16_lds_bytes(int BM) { return p16_main_bytes(BM) + 2 * BM * 4; }   // + per-row (mean, rstd)
+constexpr int p16_main_bytes(int BM, int NST) { return NST * p16_stage_bytes(BM) > p16_epi_bytes(BM) ? NST * p16_stage_bytes(BM) : p16_epi_bytes(BM); }
+constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 2 * BM * 4; }   // + per-row (mean, rstd)
 
 #define MTTS_GLDS16(gp, lp) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
-template <int BM, bool LN>
+// NST = 2: two LDS stages, the next tile requested at the top of a k-step and waited for at its end (2-3 workgroups per
+// CU hide each other's waits).  NST = 3 / 4 (small grids, <= 2 / 1 workgroups per CU, where nothing else hides the DMA
+// round trip): a ring with NST-1 tiles in flight across the barrier -- counted s_waitcnt vmcnt, raw s_barrier -- so a
+// k-step costs its MFMAs instead of a full global->LDS latency (B <= 8 serving shapes: 0.75 us -> ~0.3 us per k-step).
+template <int BM, bool LN, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     constexpr int MI = BM / 64;            // 32-row MFMA tiles per wave along M
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
     constexpr int STAGE = p16_stage_bytes(BM);
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE array: stages | epilogue tile | row statistics
-    float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM));
+    float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM, NST));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -134,36 +139,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     // fragment of v_mfma_f32_32x32x16_f16: lane (r = lane&31, h = lane>>5) holds k = 8h .. 8h+7 of a 16-wide k block
     const int fr = lane & 31, fh = lane >> 5, f8 = (fr >> 1) & 7;
     const int nk = Kp / GEMM_BK;
-    setup_run();
-    issue(0);
-    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
-    // the first tile's flight
-    if (LN) {
-        if (tid < BM) {
-            const int row = min(m0 + tid, M - 1);
-            float mean, rstd;
-            if (p.a_part) {
-                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
-                float sm = 0.f, m2 = 0.f;
-                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
-                mean = sm / (float)p.a_nparts;
-                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
-                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
-            } else {
-                mean = p.a_mean[row];
-                rstd = p.a_rstd[row];
-            }
-            srow[tid] = mean;
-            srow[BM + tid] = rstd;
-        }
-    }
-
-    __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue(buf ^ 1);   // the other buffer was last read before the barrier that ended step kt-1
-        const char* sa = lds + buf * STAGE + (wm * (BM / 2) + fr) * 128;
-        const char* sw = lds + buf * STAGE + BM * 128 + (wn * 64 + fr) * 128;
+    auto compute = [&](const char* stage) {
+        const char* sa = stage + (wm * (BM / 2) + fr) * 128;
+        const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
@@ -187,7 +165,77 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();                   // tile kt+1 landed (vmcnt(0)) and everyone is done reading tile kt
+    };
+    setup_run();
+    if constexpr (NST == 2) {
+        issue(0);
+    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
+    // the first tile's flight
+    if (LN) {
+        if (tid < BM) {
+            const int row = min(m0 + tid, M - 1);
+            float mean, rstd;
+            if (p.a_part) {
+                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
+                float sm = 0.f, m2 = 0.f;
+                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                mean = sm / (float)p.a_nparts;
+                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
+            } else {
+                mean = p.a_mean[row];
+                rstd = p.a_rstd[row];
+            }
+            srow[tid] = mean;
+            srow[BM + tid] = rstd;
+        }
+    }
+
+        __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) issue(buf ^ 1);   // the other buffer was last read before the barrier that ended step kt-1
+            compute(lds + buf * STAGE);
+            __syncthreads();                   // tile kt+1 landed (vmcnt(0)) and everyone is done reading tile kt
+        }
+    } else {
+        constexpr int D = NST - 1;             // tiles in flight: the one about to be computed + D-1 behind it
+        constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
+        for (int t = 0; t < D && t < nk; ++t) issue(t);
+    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
+    // the first tile's flight
+    if (LN) {
+        if (tid < BM) {
+            const int row = min(m0 + tid, M - 1);
+            float mean, rstd;
+            if (p.a_part) {
+                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
+                float sm = 0.f, m2 = 0.f;
+                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                mean = sm / (float)p.a_nparts;
+                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
+            } else {
+                mean = p.a_mean[row];
+                rstd = p.a_rstd[row];
+            }
+            srow[tid] = mean;
+            srow[BM + tid] = rstd;
+        }
+    }
+
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // Tile kt has landed for this wave once at most the D-1 younger tiles are outstanding (the ring's tail just
+            // drains); lgkmcnt(0): this wave's fragment reads of tile kt-1 are complete, so after the barrier that tile's
+            // stage may be refilled.  Raw s_barrier: __syncthreads() would wait for every DMA in flight.
+            if (kt + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + D < nk) issue(st + D >= NST ? st + D - NST : st + D);
+            compute(lds + st * STAGE);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        __syncthreads();                       // the epilogue tile overlays the stages: everyone is done reading
     }
 
     // ---- epilogue: park the wave's tile in LDS, re-read it as rows of float4 (16 lanes per row)
@@ -205,11 +253,11 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane);
 }
 
-template <int BM, bool LN>
+template <int BM, bool LN, int NST = 2>
 static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN>;
-    constexpr int lds_bytes = p16_lds_bytes(BM);
+    auto kern = gemm_p16_kernel<BM, LN, NST>;
+    constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -247,6 +295,14 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
         const int rounds = (tiles + 511) / 512;
         return (double)tiles / (rounds * 512.0) * ((double)M / (((M + bm - 1) / bm) * bm));
     };
+    // Small grids (serving shapes, B <= 8): 64-row tiles on the prefetch ring -- 4 stages at <= 1 workgroup per CU (96 KB
+    // of LDS), 3 stages at <= 2 (72 KB).  MTTS_P16_RING=0 keeps the two-stage kernel (A/B runs).
+    static const bool ring_on = [] { const char* e = getenv("MTTS_P16_RING"); return !(e && e[0] == '0'); }();
+    const int tiles64 = ((M + 63) / 64) * nt;
+    if (ring_on && a.force_bm == 0 && tiles64 <= 512) {
+        if (tiles64 <= 256) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
+        return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
+    }
     const bool bm64 = a.force_bm == 64 || (a.force_bm == 0 && 0.97 * fill(64) > fill(128));
     if (bm64) return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
     return ln ? launch_p16_variant<128, true>(a, s) : launch_p16_variant<128, false>(a, s);

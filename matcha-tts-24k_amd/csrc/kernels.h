@@ -127,8 +127,17 @@ struct LayerNormArgs {
 hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
 
 // GroupNorm statistics over (C/G channels x T frames) of y [B,T,C]: partial (mean, M2) per chunk of GN_CHUNK rows.
-constexpr int GN_CHUNK = 32;
-static inline int gn_chunks(int T) { return (T + GN_CHUNK - 1) / GN_CHUNK; }
+// The chunk height adapts to the batch: 32 rows when that already gives >= 512 workgroups, down to 8 rows for small batches
+// (B = 1, T = 640: 80 workgroups of 4 row passes instead of 20 of 16 -- these kernels are latency-bound there).
+constexpr int GN_CHUNK = 32;       // largest chunk
+constexpr int GN_CHUNK_MIN = 8;
+static inline int gn_chunk_rows(int B, int T) {
+    int rows = GN_CHUNK;
+    while (rows > GN_CHUNK_MIN && (long)B * ((T + rows - 1) / rows) < 512) rows >>= 1;
+    return rows;
+}
+static inline int gn_chunks(int B, int T) { const int r = gn_chunk_rows(B, T); return (T + r - 1) / r; }
+static inline int gn_chunks_max(int T) { return (T + GN_CHUNK_MIN - 1) / GN_CHUNK_MIN; }      // scratch sizing
 // tlen (optional, [B] int32): utterance b only has frames [0, tlen[b] >> tshift); statistics ignore the rest
 hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* tlen = nullptr,
                              int tshift = 0);
@@ -146,6 +155,7 @@ struct GnApplyArgs {
     const float* out16_mask = nullptr;// [B*T] multiplies the out16 copy only
     const int* tlen = nullptr;        // [B] per-utterance frame limit (>> tshift) for the statistics; null = T
     int tshift = 0;
+    int chunk_rows = 0;               // set by launch_gn_apply (gn_chunk_rows(B, T)), must match the partial pass
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

@@ -441,7 +441,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
         d.H16 = reinterpret_cast<_Float16*>(ws.f(M0 * cmax));
         d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, GEMM_BK)));
     }
-    d.gnp = ws.f((size_t)B * gn_chunks(T) * 8 * 2);
+    d.gnp = ws.f((size_t)B * gn_chunks_max(T) * 8 * 2);
     d.ldx = round_up(2 * g.n_feats, GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
     d.xmu = ws.f(M0 * d.ldx);
@@ -1263,7 +1263,7 @@ int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_m
     return 0;
 }
 
-int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G) { return (int64_t)B * gn_chunks(T) * G * 2 * (int64_t)sizeof(float); }
+int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G) { return (int64_t)B * gn_chunks_max(T) * G * 2 * (int64_t)sizeof(float); }
 
 int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_beta, const float* d_mask, int B, int T, int C, int G,
                         float eps, float* d_out, void* d_scratch, void* stream) {

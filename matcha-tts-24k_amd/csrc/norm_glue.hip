@@ -123,14 +123,14 @@ hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
 // (Chan et al.) and applies GN affine -> Mish -> mask [-> + time bias -> mask] [-> + residual].
 // Block shape: x = C/4 float4 columns, y = RT row lanes.
 __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int G, float* __restrict__ partial,
-                                  const int* __restrict__ tlen, int tshift) {
+                                  const int* __restrict__ tlen, int tshift, int chunk_rows) {
     extern __shared__ float red[];                 // [blockDim.x*blockDim.y] + [G]
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int c4 = threadIdx.x, ry = threadIdx.y, RT = blockDim.y, nth = blockDim.x * blockDim.y;
     const int tid = ry * blockDim.x + c4;
-    const int t0 = chunk * GN_CHUNK;
+    const int t0 = chunk * chunk_rows;
     const int Tb = tlen ? min(T, tlen[b] >> tshift) : T;       // this utterance's own length (per-request padding)
-    const int rows = max(0, min(GN_CHUNK, Tb - t0));
+    const int rows = max(0, min(chunk_rows, Tb - t0));
     const int cpg4 = (C / G) / 4;                  // float4 columns per group
     const float* base = y + ((size_t)b * T + t0) * C + c4 * 4;
     float* gmean = red + nth;
@@ -188,7 +188,7 @@ hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* 
     if (!y || !partial || B <= 0 || T <= 0 || !gn_shape_ok(C, G)) return hipErrorInvalidValue;
     const dim3 blk = gn_block(C);
     const size_t lds = (size_t)(blk.x * blk.y + G) * sizeof(float);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(T), B), blk, lds, s, y, T, C, G, partial, tlen, tshift);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(B, T), B), blk, lds, s, y, T, C, G, partial, tlen, tshift, gn_chunk_rows(B, T));
     return hipGetLastError();
 }
 
@@ -207,21 +207,46 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
     const int c4 = threadIdx.x, ry = threadIdx.y, RT = blockDim.y;
     const int tid = ry * blockDim.x + c4;
     const int cpg = p.C / p.G;
-    if (tid < p.G) {
+    // Merge the chunk moments (Chan et al.): L lanes per group, each folds its strided share of the chunks in chunk order,
+    // then a fixed butterfly over the L lanes -- deterministic, and a handful of dependent loads instead of nchunks of them
+    // (every workgroup repeats this merge; at B = 1 there are 80 chunks).
+    {
+        const int nth = blockDim.x * blockDim.y;
+        int L = 32;
+        while (L > 1 && L * p.G > nth) L >>= 1;
+        const int g = tid / L, j = tid - g * L;
         float n = 0.f, mean = 0.f, m2 = 0.f;
-        const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;
-        for (int k = 0; k < nchunks; ++k) {
-            if (Tb - k * GN_CHUNK <= 0) break;
-            const float* q = p.partial + (((size_t)b * nchunks + k) * p.G + tid) * 2;
-            const float nb = (float)(min(GN_CHUNK, Tb - k * GN_CHUNK) * cpg);
-            const float delta = q[0] - mean;
-            const float nt = n + nb;
-            mean += delta * (nb / nt);
-            m2 += q[1] + delta * delta * (n * nb / nt);
-            n = nt;
+        if (g < p.G) {
+            const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;
+            for (int k = j; k < nchunks; k += L) {
+                const int rows_k = min(p.chunk_rows, Tb - k * p.chunk_rows);
+                if (rows_k <= 0) break;
+                const float* q = p.partial + (((size_t)b * nchunks + k) * p.G + g) * 2;
+                const float nb = (float)(rows_k * cpg);
+                const float delta = q[0] - mean;
+                const float nt = n + nb;
+                mean += delta * (nb / nt);
+                m2 += q[1] + delta * delta * (n * nb / nt);
+                n = nt;
+            }
         }
-        smean[tid] = mean;
-        srstd[tid] = 1.0f / sqrtf(m2 / n + p.eps);
+        for (int off = 1; off < L; off <<= 1) {        // lanes of a group are contiguous and L divides 64
+            const float n2 = __shfl_xor(n, off), mean2 = __shfl_xor(mean, off), m22 = __shfl_xor(m2, off);
+            const float nt = n + n2;
+            if (nt > 0.f) {
+                const float delta = mean2 - mean;
+                // symmetric form: both partners compute the same merged triple
+                const float w2 = n2 / nt;
+                const float merged_mean = (j & off) ? mean2 + (mean - mean2) * (n / nt) : mean + delta * w2;
+                m2 = m2 + m22 + delta * delta * (n * w2);
+                mean = merged_mean;
+                n = nt;
+            }
+        }
+        if (g < p.G && j == 0) {
+            smean[g] = mean;
+            srstd[g] = 1.0f / sqrtf(m2 / n + p.eps);
+        }
     }
     __syncthreads();
     const int g = (c4 * 4) / cpg;
@@ -230,8 +255,8 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
     const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c4 * 4);
     f32x4 cb = {0.f, 0.f, 0.f, 0.f};
     if (p.chbias) cb = *reinterpret_cast<const f32x4*>(p.chbias + c4 * 4);
-    const int t0 = chunk * GN_CHUNK;
-    const int rows = min(GN_CHUNK, p.T - t0);
+    const int t0 = chunk * p.chunk_rows;
+    const int rows = min(p.chunk_rows, p.T - t0);
     for (int r = ry; r < rows; r += RT) {
         const size_t row = (size_t)b * p.T + t0 + r;
         const f32x4 v = *reinterpret_cast<const f32x4*>(p.y + row * p.C + c4 * 4);
@@ -277,7 +302,9 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
     if (a.out16 && ((a.C & 31) || a.ld16 < 2 * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.T), a.B), gn_block(a.C), 0, s, a);
+    GnApplyArgs b = a;
+    b.chunk_rows = gn_chunk_rows(a.B, a.T);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.B, a.T), a.B), gn_block(a.C), 0, s, b);
     return hipGetLastError();
 }
 
