@@ -297,13 +297,15 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     };
     // Small grids (serving shapes, B <= 8): 64-row tiles on the prefetch ring -- 4 stages at <= 1 workgroup per CU (96 KB
     // of LDS), 3 stages at <= 2 (72 KB).  MTTS_P16_RING=0 keeps the two-stage kernel (A/B runs).
-    static const bool ring_on = [] { const char* e = getenv("MTTS_P16_RING"); return !(e && e[0] == '0'); }();
+    static const int ring_mode = [] { const char* e = getenv("MTTS_P16_RING"); return e ? atoi(e) : 1; }();   // 2: ring for every 64-row grid (A/B)
+    const bool ring_on = ring_mode != 0;
     const int tiles64 = ((M + 63) / 64) * nt;
     if (ring_on && a.force_bm == 0 && tiles64 <= 512) {
         if (tiles64 <= 256) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
         return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
     }
     const bool bm64 = a.force_bm == 64 || (a.force_bm == 0 && 0.97 * fill(64) > fill(128));
+    if (bm64 && ring_mode == 2) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
     if (bm64) return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
     return ln ? launch_p16_variant<128, true>(a, s) : launch_p16_variant<128, false>(a, s);
 }

@@ -144,6 +144,7 @@ __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int
     }
 
     float s = 0.f;
+#pragma unroll 4
     for (int r = ry; r < rows; r += RT) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
         s += (v[0] + v[1]) + (v[2] + v[3]);
@@ -159,6 +160,7 @@ __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int
     __syncthreads();
     const float mu = gmean[c4 / cpg4];
     float q = 0.f;
+#pragma unroll 4
     for (int r = ry; r < rows; r += RT) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(base + (size_t)r * C) - mu;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
@@ -257,39 +259,56 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
     if (p.chbias) cb = *reinterpret_cast<const f32x4*>(p.chbias + c4 * 4);
     const int t0 = chunk * p.chunk_rows;
     const int rows = min(p.chunk_rows, p.T - t0);
-    for (int r = ry; r < rows; r += RT) {
-        const size_t row = (size_t)b * p.T + t0 + r;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p.y + row * p.C + c4 * 4);
-        const float mk = p.mask[row];
-        f32x4 o = ((v - mu) * rs) * gm + bt;
+    // U rows per pass, every load of the pass issued before the first use (the loop is a pure stream: without this each
+    // thread had one 16-byte load in flight and the kernel ran at half the HBM rate)
+    constexpr int U = 4;
+    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+    for (int r0 = ry; r0 < rows; r0 += RT * U) {
+        size_t row[U];
+        bool ok[U];
+        f32x4 v[U], rs4[U];
+        float mk[U], m16[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = mish_f(o[e]) * mk;
-        if (p.chbias) o = (o + cb) * mk;
-        if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + c4 * 4);
-        if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.C + c4 * 4) = o;
-        if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
-            using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
-            f16x4 hh, ll;
-            const float m16 = p.out16_mask ? p.out16_mask[row] : 1.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = o[e] * m16;
-                hh[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-                ll[e] = (_Float16)fminf(fmaxf((v - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
-            }
-            _Float16* o16 = p.out16 + row * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
-            *reinterpret_cast<f16x4*>(o16) = hh;
-            *reinterpret_cast<f16x4*>(o16 + 32) = ll;
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * RT;
+            ok[u] = r < rows;
+            row[u] = (size_t)b * p.T + t0 + (ok[u] ? r : rows - 1);
+            v[u] = *reinterpret_cast<const f32x4*>(p.y + row[u] * p.C + c4 * 4);
+            mk[u] = p.mask[row[u]];
+            m16[u] = p.out16_mask ? p.out16_mask[row[u]] : 1.0f;
+            if (p.res) rs4[u] = *reinterpret_cast<const f32x4*>(p.res + row[u] * p.ldr + c4 * 4);
         }
-        if (p.stats_out) {   // LayerNorm partial moments of the row's 64-column slices (16 threads = one DPP row each), as the
-                             // GEMM epilogue leaves them (gemm_f32.hip): the first transformer block needs no row_stats pass
-            const float mean = gn_allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
-            const f32x4 d = o - mean;
-            const float m2 = gn_allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
-            if ((c4 & 15) == 0) {
-                float* so = p.stats_out + (row * (size_t)(p.C >> 6) + (c4 >> 4)) * 2;
-                so[0] = mean;
-                so[1] = m2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 o = ((v[u] - mu) * rs) * gm + bt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = mish_f(o[e]) * mk[u];
+            if (p.chbias) o = (o + cb) * mk[u];
+            if (p.res) o += rs4[u];
+            if (!ok[u]) continue;                  // a whole 16-lane DPP row shares ry, so the reductions below stay uniform
+            if (p.out) *reinterpret_cast<f32x4*>(p.out + row[u] * p.C + c4 * 4) = o;
+            if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
+                f16x4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w = o[e] * m16[u];
+                    hh[e] = (_Float16)fminf(fmaxf(w, -65504.f), 65504.f);
+                    ll[e] = (_Float16)fminf(fmaxf((w - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
+                }
+                _Float16* o16 = p.out16 + row[u] * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
+                *reinterpret_cast<f16x4*>(o16) = hh;
+                *reinterpret_cast<f16x4*>(o16 + 32) = ll;
+            }
+            if (p.stats_out) {   // LayerNorm partial moments of the row's 64-column slices (16 threads = one DPP row each), as
+                                 // the GEMM epilogue leaves them: the first transformer block needs no row_stats pass
+                const float mean = gn_allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
+                const f32x4 d = o - mean;
+                const float m2 = gn_allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                if ((c4 & 15) == 0) {
+                    float* so = p.stats_out + (row[u] * (size_t)(p.C >> 6) + (c4 >> 4)) * 2;
+                    so[0] = mean;
+                    so[1] = m2;
+                }
             }
         }
     }
