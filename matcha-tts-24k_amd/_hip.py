@@ -18,7 +18,7 @@ from .hparams import PathHParams
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
-LIB = HERE / "libmtts_hip.so"
+LIB = Path(os.environ["MTTS_HIP_LIB"]) if os.environ.get("MTTS_HIP_LIB") else HERE / "libmtts_hip.so"   # override: A/B of two builds
 SOURCES = ["gemm_f32.hip", "attention_f32.hip", "gemm_p16.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
 HEADERS = [CSRC / "kernels.h", CSRC / "device_utils.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
 SOLVERS = {"euler": 0, "midpoint": 1, "rk4": 2}
