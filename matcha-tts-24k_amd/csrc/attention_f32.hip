@@ -34,9 +34,9 @@ constexpr int AT_VS = 68;     // LDS row stride of a V^T plane (halves): 136 B, 
 constexpr int AT_KS = 72;     // LDS row stride of a K plane (halves): 144 B = 9 x 16 B, conflict-free 16-byte fragment reads
 constexpr float NEG_BIG = -1e30f;
 constexpr float LOG2E = 1.44269504088896340736f;
-// exp(x) for x <= 0 as one v_exp_f32 (2^t, ~1 ulp) after an exact-to-rounding scale by log2(e): the softmax weights
-// carry ~1e-6 relative error at |x| ~ 10, far inside the path's 1e-3 budget, and cost 3 VALU ops instead of ~20.
-__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+// exp(x) = 2^(x log2 e) as one v_exp_f32 (~1 ulp); the log2(e) factor is folded into the score scale and the key bias, so
+// the softmax weights carry ~1e-6 relative error at |x| ~ 10 (far inside the path's 1e-3 budget) for 2 VALU ops per score
+// (subtract the running maximum, exponentiate) instead of ~20 for expf.
 
 // NW waves per workgroup = NW*32 queries.  NW = 4 for long sequences; NW = 2 when T is short enough that 128-query
 // blocks would leave the last block mostly empty or the grid under one round (e.g. T = 320: 3 blocks of 128 waste 17 %).
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     // ---- Q fragments for v_mfma_f32_32x32x16_f16 (B operand): lane (q = lq, half h) holds Q[q][16kb + 8h + j], j < 8,
     // kb < 4, as two fp16 terms (unscaled; the softmax scale multiplies the fp32 scores)
     const int qi = q0 + lq;
-    const bool q_in = qi < p.T;
-    bool q_ok = q_in;
-    if (p.mask_mode == 1 && q_in) q_ok = p.mask[rowbase + qi] != 0.f;
+    const bool q_in = qi < p.T;            // masked QUERY rows (boolean mode) are computed like any other: the caller multiplies
+                                           // them by the mask afterwards (text_encoder.py:236-237), so their values are don't-care
+    const float scale2 = p.scale * LOG2E;  // softmax in the log2 domain: exp(x) = exp2(x * log2 e), folded into the score FMA
     f16x8 qh[4], ql[4];
     const _Float16* q16 = p.qkv16 + head * (2 * AT_D);                       // head h = groups 2h, 2h+1 of the q section
     const _Float16* k16 = q16 + 2 * p.H * AT_D;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
             }
             if ((tid & 3) == 0) {
                 float bv = ninf;
-                if (r_in[sp]) bv = (p.mask_mode == 0) ? rbias[sp] : (rbias[sp] != 0.f ? 0.f : ninf);
-                Bs[r] = bv;
+                if (r_in[sp]) bv = (p.mask_mode == 0) ? rbias[sp] * LOG2E : (rbias[sp] != 0.f ? 0.f : ninf);
+                Bs[r] = bv;                 // key bias in the log2 domain
             }
         }
     };
@@ -224,29 +224,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + 32 * t + 8 * g4 + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = q_ok ? s[t][4 * g4 + e] * p.scale + bb[e] : ninf;
+                    const float v = fmaf(s[t][4 * g4 + e], scale2, bb[e]);     // log2 domain: one FMA per score
                     s[t][4 * g4 + e] = v;
                     mx = fmaxf(mx, v);
                 }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp_neg(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp_neg(s[t][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
                 s[t][r] = pv;
                 psum += pv;
             }
         l_run = l_run * alpha + psum;
+        if (__any(m_new != m_run)) {       // the running maximum moved for some query of this wave: rescale (else alpha == 1)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         // ---- O^T += V^T . P^T on split f16 operands
 #pragma unroll
         for (int t = 0; t < 2; ++t)

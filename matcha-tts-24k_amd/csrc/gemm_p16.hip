@@ -304,7 +304,9 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
         if (tiles64 <= 256) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
         return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
     }
-    const bool bm64 = a.force_bm == 64 || (a.force_bm == 0 && 0.97 * fill(64) > fill(128));
+    static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();   // A/B runs only
+    const int force = a.force_bm ? a.force_bm : env_bm;
+    const bool bm64 = force == 64 || (force == 0 && 0.97 * fill(64) > fill(128));
     if (bm64 && ring_mode == 2) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
     if (bm64) return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
     return ln ? launch_p16_variant<128, true>(a, s) : launch_p16_variant<128, false>(a, s);
