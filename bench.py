@@ -233,6 +233,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()              # the other ranks wait here while rank 0 finishes its per-kernel event pass
         dist.destroy_process_group()
 
 
