@@ -8,13 +8,13 @@
 // Work split: one workgroup per (batch, head, block of 128 or 64 queries), each of its 4 or 2 waves 32 of them.  Keys/values stream through LDS in tiles of 64 (global -> registers prefetch -> LDS).
 // Both products run in the "transposed" orientation so that the query sits on the lane:
 //   S^T[key][q] = K[key][:] . Q[q][:]     A = K fragment (LDS, ds_read_b128), B = Q fragment (registers, loaded once)
-//   O^T[d][q]  += V^T[d][key] . P^T[key][q]   A = V column (LDS, ds_read_b32), B = the S^T accumulator itself
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]   A = V column (LDS, transposed by ds_read_b64_tr_b16), B = the S^T accumulator itself
 // Both run on the f16 matrix pipe with split operands (x = h + l, h = fp16(x), l = fp16(x - h); products h.h + h.l + l.h,
 // fp32 accumulate: 3 v_mfma_f32_32x32x16_f16 per 16-deep block instead of 8 v_mfma_f32_32x32x2_f32).  q, k, v are O(1)
 // and p <= 1, so the residuals stay representable (absolute error ~3e-8 per operand); the softmax scale multiplies the
 // fp32 scores.  The S^T accumulator feeds P.V without leaving registers: registers 8s..8s+7 of a 32-key sub-tile are the
-// B fragment of key block s in the permuted key order 16s + 8(j>>2) + 4h + (j&3), and V is staged TRANSPOSED ([d][key])
-// so that the matching A fragment is two 8-byte LDS reads.
+// B fragment of key block s in the permuted key order 16s + 8(j>>2) + 4h + (j&3); V is staged row-major and the matching A
+// fragment is two transposing LDS reads (ds_read_b64_tr_b16: 4 keys x 16 d per 16-lane group).
 // so the softmax row (max, sum) is a reduction over the lane's own registers plus one cross-half shuffle, the
 // probabilities never leave registers, and the per-query rescale is a lane-uniform multiply of the O^T accumulators.
 // Head dims below 64 (encoder: 48) are zero-padded to 64 in the staged tiles.
@@ -30,7 +30,6 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int AT_QW = 32;     // queries per wave (one 32-column MFMA tile)
 constexpr int AT_K = 64;      // keys per tile
 constexpr int AT_D = 64;      // padded head dim
-constexpr int AT_VS = 68;     // LDS row stride of a V^T plane (halves): 136 B, conflict-free 8-byte column-group reads
 constexpr int AT_KS = 72;     // LDS row stride of a K plane (halves): 144 B = 9 x 16 B, conflict-free 16-byte fragment reads
 constexpr float NEG_BIG = -1e30f;
 constexpr float LOG2E = 1.44269504088896340736f;
@@ -43,13 +42,22 @@ constexpr float LOG2E = 1.44269504088896340736f;
 // P16: q|k|v rows arrive as a P16 image with UNSCALED residuals (written by the q|k|v projection's epilogue, gemm_p16.hip)
 // and the output leaves as a P16 image with the 2^11-scaled residual for the out-projection: no split arithmetic on the
 // way in, one per output element on the way out.  Head dim 64 only (a head = 256 contiguous bytes of the row).
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of halves leaves LDS column-major (EXEC must be full)
+__device__ __forceinline__ f16x4 tr_read4(const _Float16* lds_ptr) {
+    typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const h4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(lds_ptr));
+    return __builtin_bit_cast(f16x4, v);
+}
+
 template <int NW, bool P16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
     constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
     __shared__ __attribute__((aligned(16))) _Float16 Ks[2 * AT_K * AT_KS];   // planes h | l
-    __shared__ __attribute__((aligned(16))) _Float16 Vt[2 * AT_D * AT_VS];   // V^T planes h | l: [d][key]
+    // V planes h | l, row-major and split by d half: [plane][d >> 5][key][d & 31] (64-byte rows, no padding).  P.V needs V^T
+    // fragments; ds_read_b64_tr_b16 transposes 4 keys x 16 d blocks on the way out of LDS, so staging is plain row stores.
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[2 * 2 * AT_K * 32];
     __shared__ __attribute__((aligned(16))) float Bs[AT_K];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,9 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     const f32x4 kraw = r_in[sp] ? rk[sp][c] : zero;
                     *reinterpret_cast<f32x4*>(Ks + plane * AT_K * AT_KS + r * AT_KS + d) = kraw;
                     const f32x4 vraw = r_in[sp] ? rv[sp][c] : zero;
-                    const f16x8 vv = __builtin_bit_cast(f16x8, vraw);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) Vt[plane * AT_D * AT_VS + (d + e) * AT_VS + r] = vv[e];   // transposing 16-bit stores
+                    *reinterpret_cast<f32x4*>(Vs + ((plane * 2 + (c >> 1)) * AT_K + r) * 32 + 8 * (tid & 3)) = vraw;
                 }
             } else
 #pragma unroll
@@ -176,12 +182,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 *reinterpret_cast<f16x4*>(Ks + r * AT_KS + sd + 16 * c) = kh;
                 *reinterpret_cast<f16x4*>(Ks + AT_K * AT_KS + r * AT_KS + sd + 16 * c) = kl;
                 const f32x4 vv = ok ? rv[sp][c] : zero;
+                f16x4 vh4, vl4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {          // transposing 16-bit stores: Vt[d][key]
+                for (int e = 0; e < 4; ++e) {
                     const _Float16 a = (_Float16)vv[e];
-                    Vt[(sd + 16 * c + e) * AT_VS + r] = a;
-                    Vt[AT_D * AT_VS + (sd + 16 * c + e) * AT_VS + r] = (_Float16)(vv[e] - (float)a);
+                    vh4[e] = a;
+                    vl4[e] = (_Float16)(vv[e] - (float)a);
                 }
+                const int dcol = sd + 16 * c;              // 4 consecutive d of key r
+                *reinterpret_cast<f16x4*>(Vs + ((dcol >> 5) * AT_K + r) * 32 + (dcol & 31)) = vh4;
+                *reinterpret_cast<f16x4*>(Vs + ((2 + (dcol >> 5)) * AT_K + r) * 32 + (dcol & 31)) = vl4;
             }
             if ((tid & 3) == 0) {
                 float bv = ninf;
@@ -265,10 +275,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 const int k0 = 32 * t + 16 * ks + 4 * h;       // this lane half's keys: k0..k0+3 and k0+8..k0+11
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const _Float16* vp = Vt + (32 * dt + lq) * AT_VS + k0;
+                    // transposed reads: the 16-lane group g = lane>>4 takes the block keys k0..k0+3 x d 32 dt + 16 (g&1) ..+15;
+                    // lane 4q+p of the group addresses key k0+q, columns 4p..4p+3, and receives column lane&15 of the 4 keys
+                    const _Float16* vp = Vs + ((dt * AT_K) + k0 + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
                     f16x8 vh, vl;
-                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(vp), h1 = *reinterpret_cast<const f16x4*>(vp + 8);
-                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(vp + AT_D * AT_VS), l1 = *reinterpret_cast<const f16x4*>(vp + AT_D * AT_VS + 8);
+                    const f16x4 h0 = tr_read4(vp), h1 = tr_read4(vp + 8 * 32);
+                    const f16x4 l0 = tr_read4(vp + 2 * AT_K * 32), l1 = tr_read4(vp + 2 * AT_K * 32 + 8 * 32);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
