@@ -49,7 +49,8 @@ __device__ __forceinline__ f16x4 tr_read4(const _Float16* lds_ptr) {
     return __builtin_bit_cast(f16x4, v);
 }
 
-template <int NW, bool P16>
+// ONE (with P16): the opt-in fp16 mode -- heads x heads products only (see gemm_p16.hip).
+template <int NW, bool P16, bool ONE = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
@@ -220,8 +221,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
             for (int kb = 0; kb < 4; ++kb) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(kp + 16 * kb);
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + AT_K * AT_KS + 16 * kb);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
+                if constexpr (!ONE) {
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
+                }
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], s[t], 0, 0, 0);
             }
         }
@@ -283,8 +286,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     const f16x4 l0 = tr_read4(vp + 2 * AT_K * 32), l1 = tr_read4(vp + 2 * AT_K * 32 + 8 * 32);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+                    if constexpr (!ONE) {
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+                    }
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
                 }
             }
@@ -339,10 +344,12 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const long blocks128 = (long)b128 * a.H * a.B;
     const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
     if (blocks128 >= 768 && waste128 < 0.1) {
-        if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        else if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
     } else {
-        if (p16) hipLaunchKernelGGL((attention_f32_kernel<2, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        else if (p16) hipLaunchKernelGGL((attention_f32_kernel<2, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<2, false>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
     }
     return hipGetLastError();

@@ -43,7 +43,9 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // CU hide each other's waits).  NST = 3 / 4 (small grids, <= 2 / 1 workgroups per CU, where nothing else hides the DMA
 // round trip): a ring with NST-1 tiles in flight across the barrier -- counted s_waitcnt vmcnt, raw s_barrier -- so a
 // k-step costs its MFMAs instead of a full global->LDS latency (B <= 8 serving shapes: 0.75 us -> ~0.3 us per k-step).
-template <int BM, bool LN, int NST>
+// ONE: the opt-in fp16 mode (MTTS_GEMM_TERMS=1): only the head planes are multiplied (one MFMA per 16-deep block instead of
+// three, half the fragment reads) -- fp16 operand precision with fp32 accumulation, what torch.autocast gives the reference.
+template <int BM, bool LN, int NST, bool ONE>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     constexpr int MI = BM / 64;            // 32-row MFMA tiles per wave along M
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
@@ -149,19 +151,21 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sh);
-                al[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sl);
+                if constexpr (!ONE) al[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sl);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sh);
-                bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sl);
+                if constexpr (!ONE) bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sl);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    if constexpr (!ONE) {
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -253,10 +257,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane);
 }
 
-template <int BM, bool LN, int NST = 2>
-static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
+template <int BM, bool LN, int NST, bool ONE>
+static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST>;
+    auto kern = gemm_p16_kernel<BM, LN, NST, ONE>;
     constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -267,6 +271,11 @@ static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
     const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int BM, bool LN, int NST = 2>
+static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
+    return a.fast16 ? launch_p16_one<BM, LN, NST, true>(a, s) : launch_p16_one<BM, LN, NST, false>(a, s);
 }
 
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {

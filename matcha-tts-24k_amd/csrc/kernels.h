@@ -65,6 +65,7 @@ struct GemmArgs {
     int ld16 = 0;                     // its row stride in halves
     float out_lscale = 2048.0f;       // residual scale of out16: 2048 for GEMM operands, 1 for the attention kernel's q|k|v
     const float* out16_mask = nullptr;// [rows] multiplies the out16 copy only (conv consumers read masked rows; out stays as is)
+    bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
@@ -105,6 +106,7 @@ struct AttnArgs {
     float out_lscale = 2048.0f;
     const int* tlen = nullptr;    // [B] per-utterance frame limit (>> tshift): keys at or beyond it do not exist; null = T
     int tshift = 0;
+    bool fast16 = false;          // P16 I/O only: single fp16 product per MAC (no residual terms)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }

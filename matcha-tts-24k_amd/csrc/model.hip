@@ -358,6 +358,7 @@ static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
     a.w16 = c->gemm_terms ? static_cast<const void*>(W(c, p.w16)) : nullptr;
     a.bias = p.has_bias ? W(c, p.b) : nullptr;
     a.wsum = c->gemm_terms == 2 ? W(c, p.wsum) : nullptr;
+    a.fast16 = c->fast16;
     a.N = p.N;
     a.ntaps = p.ntaps;
     a.ktap = p.ktap;
@@ -538,7 +539,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         AttnArgs at;
         at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.mask[lvl];
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl;
+        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl; at.fast16 = c->fast16;
         RET_IF(run_attn(c, at, s));
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -569,7 +570,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
     RET_IF(run_gemm(c, q, s));
     AttnArgs at;
     at.qkv = d.QKV; at.mask = d.mask[lvl]; at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl;
+    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl; at.fast16 = c->fast16;
     RET_IF(run_attn(c, at, s));
     GemmArgs o;
     panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -859,6 +860,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     mtts_ctx* c = new mtts_ctx();
     c->cfg = g;
     c->gemm_terms = default_gemm_terms();
+    { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; }     // 1 = fp16 mode on the P16 kernels (images as for 2)
     { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
     return c;
 }
@@ -1277,7 +1279,7 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
 }
 
 // ------------------------------------------------------------------------------------------------ measurement
-int mtts_gemm_terms(mtts_ctx* c) { return c ? c->gemm_terms : default_gemm_terms(); }
+int mtts_gemm_terms(mtts_ctx* c) { return c ? (c->fast16 ? 1 : c->gemm_terms) : default_gemm_terms(); }
 
 int mtts_prof_enable(mtts_ctx* c, int on) {
     if (!c) { set_error("null context"); return -1; }

@@ -218,6 +218,26 @@ def test_prod_fp32_operand_path_vs_golden(prod, synthetic, dev, monkeypatch):
     assert maxabs(out["mel"], ref["mel"]) < 2e-4
 
 
+def test_prod_fp16_mode_is_opt_in_and_looser(prod, synthetic, dev, monkeypatch):
+    """MTTS_GEMM_TERMS=1 (read when the context is created): the estimator multiplies only the fp16 head planes -- fp16 operand
+    precision with fp32 accumulation, the arithmetic torch.autocast gives the reference on a GPU (reference inference.py:238).
+    Opt-in: an order of magnitude looser than the default, so it must stay within 5e-2 of the fp32 golden (|mel| ~ 40) and the
+    default must not be it."""
+    hp, sd, model = prod
+    g = np.load(GOLDEN / "prod_synth.npz")
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
+    z = synthetic.cpu_noise((1, 100, 640)).to(dev)
+    monkeypatch.setenv("MTTS_GEMM_TERMS", "1")
+    fast = make_model(hp, sd, dev)
+    fast.decoder.solver = "euler"
+    out = fast.synthesise(x.to(dev), x_len.to(dev), 10, speaker=0, z=z)
+    assert fast.hip.gemm_terms() == 1
+    monkeypatch.delenv("MTTS_GEMM_TERMS")
+    err = maxabs(out["mel"], _t(g["mel_euler10"]))
+    assert MEL_TOL < err < 5e-2, err
+    assert model.hip.gemm_terms() == 2
+
+
 def test_prod_ragged_batch_vs_golden(hparams, synthetic, dev):
     hp = hparams.prod_v20(n_spks=3)
     sd = synthetic.make_state_dict(hp, seed=7)
