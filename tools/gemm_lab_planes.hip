@@ -18,6 +18,9 @@
 #ifndef BIG
 #define BIG 0
 #endif
+#ifndef BUF
+#define BUF 0   // 1 (with ILV): tiles by buffer_load ... lds (SGPR base + fixed per-lane offsets) instead of global_load_lds
+#endif
 #ifndef MINB
 #define MINB 2
 #endif
@@ -67,7 +70,27 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes(const h16* __restrict__
     // DMA sources: a wave moves pieces 2*wave, 2*wave+1 (16 rows x 64 B each) of every plane.  Lane i of a piece fills LDS
     // bytes [16 i, 16 i + 16): row i>>2, slot i&3, which holds k-chunk (i&3) ^ ((row>>2)&3) (the read side applies the same
     // involution: rule "swizzle both sides").
-#if ILV
+#if ILV && BUF
+    // buffer form: one resource per operand, per-lane byte offsets fixed for the whole kernel, the k-step enters as soffset
+    auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ah, 0, (int)((size_t)M * K * 4), 0x00020000);
+    auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wh, 0, (int)((size_t)N * K * 4), 0x00020000);
+    int offA[4], offW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j, rr = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((piece & 1) * 4 + (lane >> 4)) & 7);
+        offA[j] = (min(row0 + rr, M - 1) * K * 2 + chunk * 8) * 2;
+        offW[j] = ((col0 + rr) * K * 2 + chunk * 8) * 2;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = lds + buf * STAGE_B + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, offA[j], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(base + 2 * PLANE_B + j * 1024), 16, offW[j], kt * 128, 0, 0);
+        }
+    };
+#elif ILV
     // piece = 8 rows x 128 B (h|l of one 32-k group); a wave moves pieces 4*wave .. 4*wave+3 of A and of W
     const h16* srcA[4]; const h16* srcW[4];
 #pragma unroll
@@ -327,7 +350,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("planes BIG=%d ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", BIG, ILV, NBUF, MINB, M, N, K, grid,
+    printf("planes BUF=%d BIG=%d ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", BUF, BIG, ILV, NBUF, MINB, M, N, K, grid,
            LDS_BYTES, us, tf, maxerr, maxref);
     return 0;
 }
