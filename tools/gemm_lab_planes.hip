@@ -21,6 +21,9 @@
 #ifndef BUF
 #define BUF 0   // 1 (with ILV): tiles by buffer_load ... lds (SGPR base + fixed per-lane offsets) instead of global_load_lds
 #endif
+#ifndef VAR
+#define VAR 0   // ablations of the 2-stage loop: 1 = no DMA after the first tile, 2 = DMA + barriers but no fragment reads / MFMAs
+#endif
 #ifndef MINB
 #define MINB 2
 #endif
@@ -144,8 +147,45 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes(const h16* __restrict__
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = (NBUF == 2) ? (kt & 1) : 0;
-        if (NBUF == 2 && kt + 1 < nk) issue(kt + 1, buf ^ 1);
-        const char* sb = lds + buf * STAGE_B;
+#if VAR == 3
+        {   // kb = 0 fragments first, THEN the next tile's requests, so the matrix pipe has work while the DMAs issue
+            const char* sb = lds + buf * STAGE_B;
+            const int f8 = (fr >> 1) & 7;
+            h16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+            auto rd = [&](int kb) {
+                const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ro = (wm * 64 + i * 32 + fr) * 128;
+                    ah[kb][i] = *reinterpret_cast<const h16x8*>(sb + ro + sh);
+                    al[kb][i] = *reinterpret_cast<const h16x8*>(sb + ro + sl);
+                    const int co = 2 * PLANE_B + (wn * 64 + i * 32 + fr) * 128;
+                    bh[kb][i] = *reinterpret_cast<const h16x8*>(sb + co + sh);
+                    bl[kb][i] = *reinterpret_cast<const h16x8*>(sb + co + sl);
+                }
+            };
+            auto mm = [&](int kb) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bl[kb][j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb][i], bh[kb][j], accx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bh[kb][j], acc[i][j], 0, 0, 0);
+                    }
+            };
+            rd(0);
+            rd(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+            mm(1);
+        }
+#else
+        if (NBUF == 2 && kt + 1 < nk && VAR != 1) issue(kt + 1, buf ^ 1);
+        const char* sb = lds + (VAR == 1 ? 0 : buf) * STAGE_B;
+#if VAR != 2
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             h16x8 ah[2], al[2], bh[2], bl[2];
@@ -182,6 +222,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes(const h16* __restrict__
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+#endif
+#endif
         __syncthreads();
         if (NBUF == 1 && kt + 1 < nk) { issue(kt + 1, 0); __syncthreads(); }
     }
@@ -350,7 +392,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("planes BUF=%d BIG=%d ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", BUF, BIG, ILV, NBUF, MINB, M, N, K, grid,
+    printf("planes VAR=%d BUF=%d BIG=%d ILV=%d NBUF=%d MINB=%d M=%d N=%d K=%d grid=%d lds=%d: %.1f us  %.1f TF-eq  maxerr %.3g (max|ref| %.3g)\n", VAR, BUF, BIG, ILV, NBUF, MINB, M, N, K, grid,
            LDS_BYTES, us, tf, maxerr, maxref);
     return 0;
 }
