@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
 
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns
-    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    const bool vec = ((p.N & 3) == 0) && (!p.out || (p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
     if (vec) {     // the common case: unrolled, residuals prefetched, activation chosen once (gemm_epilogue.h)
         gemm_epilogue_rows<BM, false>(p, Cw, nullptr, M, m0, n0, wm, wn, lane);
         return;
@@ -454,7 +454,9 @@ static hipError_t launch_terms(const GemmArgs& a, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.a16_0) return launch_gemm_p16(a, s);     // operands already split in memory: gemm_p16.hip
     // shape contract (the kernel indexes without further checks)
-    if (!a.a0 || (!a.w && !a.w16) || !a.out || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
+    if (!a.a0 || (!a.w && !a.w16) || (!a.out && !a.out16) || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
+    // a P16 copy of the result (the consumer is a P16 GEMM) needs the vectorised epilogue; out may then be null
+    if (a.out16 && ((a.N % 32) || a.ld16 < 2 * a.N || (a.ld16 & 3) || (a.out && (a.ldc & 3)) || (a.res && (a.ldr & 3)))) return hipErrorInvalidValue;
     if (a.ntaps < 1 || a.ntaps > MAX_TAPS) return hipErrorInvalidValue;
     if (a.ktap % GEMM_BK != 0 || a.ktap < a.c0 + a.c1) return hipErrorInvalidValue;
     if ((a.c0 & 3) || (a.c1 & 3) || (a.lda0 & 3) || (a.lda1 & 3)) return hipErrorInvalidValue;

@@ -1072,14 +1072,22 @@ int mtts_text_encoder_forward(mtts_ctx* c, const int64_t* d_x, const int64_t* d_
         n1.x = e.H2; n1.ldx = Hd; n1.y = e.H; n1.ldy = Hd; n1.M = M; n1.C = Hd; n1.T = Tx;
         n1.gamma = W(c, E.n1_g[l].off); n1.beta = W(c, E.n1_b[l].off); n1.mask = xm;
         LAUNCH(c, 2, 0, s, launch_layernorm(n1, s));
+        // FFN: conv k5 -> ReLU -> mask -> conv k5.  The second conv is the encoder's long-K GEMM (K = 5 x filter) on a grid
+        // far under one round of workgroups: in the fp16-split mode the hidden layer is handed over as a masked P16 image
+        // (written by the first conv's epilogue) so that it runs on gemm_p16.hip's prefetch ring (198 -> ~80 us at B = 32).
+        const bool ffn_p16 = c->p16_on && c->gemm_terms == 2 && (g.enc_filter % 32) == 0;
+        _Float16* F16 = reinterpret_cast<_Float16*>(e.F1);        // same bytes as the fp32 hidden layer
         GemmArgs f1;
         panel_args(c, E.ffn1[l], f1); rows_plain(f1, B, Tx); taps_centered(f1, g.enc_kernel);
-        f1.a0 = e.H; f1.lda0 = Hd; f1.c0 = Hd; f1.act = ACT_RELU; f1.out = e.F1; f1.ldc = g.enc_filter;
+        f1.a0 = e.H; f1.lda0 = Hd; f1.c0 = Hd; f1.act = ACT_RELU;
+        if (ffn_p16) { f1.out16 = F16; f1.ld16 = 2 * g.enc_filter; f1.out16_mask = xm; }
+        else { f1.out = e.F1; f1.ldc = g.enc_filter; }
         RET_IF(run_gemm(c, f1, s));
         GemmArgs f2;
         panel_args(c, E.ffn2[l], f2); rows_plain(f2, B, Tx); taps_centered(f2, g.enc_kernel);
-        f2.a0 = e.F1; f2.lda0 = g.enc_filter; f2.c0 = g.enc_filter; f2.a_mask = xm; f2.out_mask = xm;
-        f2.res = e.H; f2.ldr = Hd; f2.out = e.H2; f2.ldc = Hd;
+        if (ffn_p16) { f2.a16_0 = F16; f2.lda16_0 = 2 * g.enc_filter; f2.c0 = g.enc_filter; f2.fast16 = false; }   // durations: full precision
+        else { f2.a0 = e.F1; f2.lda0 = g.enc_filter; f2.c0 = g.enc_filter; f2.a_mask = xm; }
+        f2.out_mask = xm; f2.res = e.H; f2.ldr = Hd; f2.out = e.H2; f2.ldc = Hd;
         RET_IF(run_gemm(c, f2, s));
         LayerNormArgs n2 = n1;
         n2.gamma = W(c, E.n2_g[l].off); n2.beta = W(c, E.n2_b[l].off);
