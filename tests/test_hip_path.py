@@ -238,6 +238,22 @@ def test_prod_fp16_mode_is_opt_in_and_looser(prod, synthetic, dev, monkeypatch):
     assert model.hip.gemm_terms() == 2
 
 
+def test_prod_rk4_and_voice_mix_vs_oracle(hparams, synthetic, oracle, dev):
+    """The solver and speaker paths the goldens do not cover at production shapes (P16 estimator): rk4 (3/8 rule, four
+    evaluations per step through ode_combine) and a two-voice mix, against the oracle run here on the same inputs."""
+    hp = hparams.prod_v20(n_spks=3)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    model = make_model(hp, sd, dev)
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 24, seed=77)
+    z = synthetic.cpu_noise((1, 100, 120)).to(dev)
+    mix = [(0, 0.25), (2, 0.75)]
+    model.decoder.solver = "rk4"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, voice_mix=mix, z=z)
+    ref = oracle.synthesise(sd, hp, x, x_len, 2, voice_mix=mix, solver="rk4", z=z.cpu())
+    assert out["mel"].shape == ref["mel"].shape
+    assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
+
+
 def test_prod_ragged_batch_vs_golden(hparams, synthetic, dev):
     hp = hparams.prod_v20(n_spks=3)
     sd = synthetic.make_state_dict(hp, seed=7)
