@@ -1,7 +1,7 @@
 // Shared GEMM epilogue (gemm_f32.hip, gemm_p16.hip): the wave's BM/2 x 64 tile is parked in LDS (row stride GEMM_CS
 // floats) and re-read as rows of float4, 16 lanes per row, so every store instruction writes whole 256-byte row pieces.
 //
-//   c = act(LN'(acc) + bias);  c *= out_mask[row];  c *= out_scale;  c += res[row][n]
+//   c = act(LN'(acc) + bias);  c *= out_mask[row];  c *= out_scale;  c += res[row][n]   (res: fp32 rows or a P16 image)
 //   -> fp32 rows (out) and/or a P16 image (out16, optionally times out16_mask[row]); optional 64-column partial moments
 //      (stats_out)
 //
@@ -37,7 +37,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
     }
     auto run = [&](auto act_c, auto res_c) {
         constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
-        constexpr bool RES = decltype(res_c)::value != 0;
+        constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows (p.res), 2 a P16 image (p.res16)
+        constexpr bool RES = RESK == 1;
         // chunks of U passes (4 U rows of the tile): all of a chunk's residual / mask loads are in flight together
         constexpr int U = 4;
         for (int c0 = 0; c0 < NIT; c0 += U) {
@@ -45,6 +46,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
             bool ok[U];
             float om[U], om16[U];
             f32x4 rres[RES ? U : 1];
+            f16x4 r16h[RESK == 2 ? U : 1], r16l[RESK == 2 ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int m = m0 + wm * (BM / 2) + (c0 + u) * 4 + (lane >> 4);
@@ -59,6 +61,12 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
                 om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
                 if constexpr (RES) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
+                if constexpr (RESK == 2) {
+                    const int ncl = col_ok ? nc : 0;
+                    const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
+                    r16h[u] = *reinterpret_cast<const f16x4*>(q);
+                    r16l[u] = *reinterpret_cast<const f16x4*>(q + 32);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -81,6 +89,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 o *= om[u];
                 if (p.out_scale != 1.0f) o *= p.out_scale;
                 if constexpr (RES) o += rres[u];
+                if constexpr (RESK == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += (float)r16h[u][e] + (float)r16l[u][e] * (1.0f / F16_RES_SCALE);
+                }
                 if (ok[u]) {
                     if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)orow[u] * p.ldc + nc) = o;
                     if (p.out16) {                           // P16 copy: 8 lanes write one whole 128-B line
@@ -110,7 +122,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         }
     };
     const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
-    if (p.res) {
+    if (p.res16) {             // the residual stream kept only as a P16 image (decoder transformer blocks)
+        if (actk == 0) run(IntC<0>{}, IntC<2>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<2>{});
+        else run(IntC<2>{}, IntC<2>{});
+    } else if (p.res) {
         if (actk == 0) run(IntC<0>{}, IntC<1>{});
         else if (actk == 1) run(IntC<1>{}, IntC<1>{});
         else run(IntC<2>{}, IntC<1>{});

@@ -453,6 +453,7 @@ static hipError_t launch_terms(const GemmArgs& a, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.a16_0) return launch_gemm_p16(a, s);     // operands already split in memory: gemm_p16.hip
+    if (a.res16) return hipErrorInvalidValue;      // P16 residuals: gemm_p16.hip only
     // shape contract (the kernel indexes without further checks)
     if (!a.a0 || (!a.w && !a.w16) || (!a.out && !a.out16) || a.N <= 0 || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0) return hipErrorInvalidValue;
     // a P16 copy of the result (the consumer is a P16 GEMM) needs the vectorised epilogue; out may then be null

@@ -293,6 +293,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (ln && (!a.wsum || a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0 || a.T_in != a.T_out)) return hipErrorInvalidValue;
     if (a.out && (a.ldc & 3)) return hipErrorInvalidValue;
     if (a.res && (a.ldr & 3)) return hipErrorInvalidValue;
+    if (a.res16 && (a.res || (a.N % 32) || a.ldr16 < 2 * a.N || (a.ldr16 & 3))) return hipErrorInvalidValue;
     if (a.out16 && ((a.N % 32) || a.ld16 < 2 * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;

@@ -65,6 +65,8 @@ struct GemmArgs {
     int ld16 = 0;                     // its row stride in halves
     float out_lscale = 2048.0f;       // residual scale of out16: 2048 for GEMM operands, 1 for the attention kernel's q|k|v
     const float* out16_mask = nullptr;// [rows] multiplies the out16 copy only (conv consumers read masked rows; out stays as is)
+    const _Float16* res16 = nullptr;  // residual as a P16 image (2^11-scaled residual plane) instead of fp32 rows; N % 32 == 0
+    int ldr16 = 0;                    // its row stride in halves; may alias out16 (in-place update of the residual stream)
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);

@@ -543,8 +543,10 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         RET_IF(run_attn(c, at, s));
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
-        o.a16_0 = ATT16; o.lda16_0 = 2 * inner; o.c0 = inner; o.res = x; o.ldr = C; o.out = x; o.ldc = C;
+        o.a16_0 = ATT16; o.lda16_0 = 2 * inner; o.c0 = inner;
         o.out16 = d.X16; o.ld16 = 2 * C; o.stats_out = d.lnp;
+        if (d.p16) { o.res16 = d.X16; o.ldr16 = 2 * C; }      // P16 decoder: the residual stream exists only as its image
+        else { o.res = x; o.ldr = C; o.out = x; o.ldc = C; }
         RET_IF(run_gemm(c, o, s));
         GemmArgs f1;
         panel_args(c, t.ff1, f1); rows_plain(f1, B, T);
@@ -553,7 +555,9 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         RET_IF(run_gemm(c, f1, s));
         GemmArgs f2;
         panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
-        f2.a16_0 = FF16; f2.lda16_0 = 8 * C; f2.c0 = 4 * C; f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C;
+        f2.a16_0 = FF16; f2.lda16_0 = 8 * C; f2.c0 = 4 * C;
+        if (d.p16) { f2.res16 = d.X16; f2.ldr16 = 2 * C; }
+        else { f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C; }
         if (emit_stats) { f2.stats_out = d.lnp; f2.out16 = d.X16; f2.ld16 = 2 * C; }
         else if (last16) { f2.out16 = last16; f2.ld16 = 2 * C; f2.out16_mask = d.mask[lvl]; }
         RET_IF(run_gemm(c, f2, s));
@@ -722,7 +726,8 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
     g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
-    g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
+    g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;          // no fp32 copy: x lives on as its image only
+    (void)out;
     g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
     LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
     return 0;
