@@ -109,7 +109,7 @@ int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_
  * so an utterance's mel depends on what it was batched with.  With d_t_len[b] (device int32, even, <= T) set, the next
  * mtts_decoder_forward / mtts_cfm_solve calls treat utterance b as if only frames [0, d_t_len[b]) existed: GroupNorm
  * statistics and attention keys stop there (convolutions already read masked zeros beyond it), so every utterance of a
- * ragged batch gets exactly the values of a batch-of-one call.  NULL restores whole-batch padding.  The pointer is kept,
+ * ragged batch gets the values of a batch-of-one call (up to the summation order of differently shaped tiles).  NULL restores whole-batch padding.  The pointer is kept,
  * not copied: it must stay valid until replaced. */
 int mtts_set_frame_limits(mtts_ctx* ctx, const int32_t* d_t_len);
 

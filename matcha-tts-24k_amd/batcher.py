@@ -3,7 +3,7 @@
 The reference server handles one request at a time on the event-loop thread (server.py:93-127).  On an MI355X one request
 uses a few percent of the chip (batch sweep), so a serving process wants to run whatever is waiting as
 ONE ragged batch -- without changing any request's audio.  ``per_request_padding`` (inference.py) makes that exact: each row
-of the batch equals the batch-of-one result.
+of the batch equals the batch-of-one result (to rounding: tile shapes, hence summation order, depend on the grid).
 
 ``FrameBudgetBatcher`` is the queue + grouping policy:
   * requests are grouped by what must be uniform inside one call (solver, n_timesteps, scale_correction, length_scale);

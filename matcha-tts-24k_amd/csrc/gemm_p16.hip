@@ -1,7 +1,7 @@
 // GEMM / implicit conv1d on operands that are ALREADY fp16-split in memory ("P16" images, kernels.h) for gfx950.
 //
 // Same arithmetic as gemm_f32.hip's TERMS = 2 mode (x = h + l / 2^11, products h.h + (h.l + l.h) / 2^11 accumulated in fp32
-// by three v_mfma_f32_32x32x16_f16 per 16-deep block, two accumulators), but the producer of the activations has done the
+// by three v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block, two accumulators), but the producer of the activations has done the
 // split once, in its epilogue, so this kernel's loop has no split arithmetic, no staging registers and no LDS stores: both
 // tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per k-step.
 //
@@ -45,9 +45,9 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // k-step costs its MFMAs instead of a full global->LDS latency (B <= 8 serving shapes: 0.75 us -> ~0.3 us per k-step).
 // ONE: the opt-in fp16 mode (MTTS_GEMM_TERMS=1): only the head planes are multiplied (one MFMA per 16-deep block instead of
 // three, half the fragment reads) -- fp16 operand precision with fp32 accumulation, what torch.autocast gives the reference.
-template <int BM, bool LN, int NST, bool ONE>
+// M16: v_mfma_f32_16x16x32_f16 tiles (MT x 4 per wave) instead of 32x32x16 (MI x 2).
+template <int BM, bool LN, int NST, bool ONE, bool M16>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
-    constexpr int MI = BM / 64;            // 32-row MFMA tiles per wave along M
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
     constexpr int STAGE = p16_stage_bytes(BM);
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE array: stages | epilogue tile | row statistics
@@ -130,23 +130,61 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         }
     };
 
-    f32x16 acc[MI][2], accx[MI][2];
+    // v_mfma_f32_16x16x32_f16 tiles (MT x 4 per wave; one instruction spans the whole 32-deep k-step): on random operands the
+    // chip holds a higher clock with this shape than with 32x32x16 at equal cycles per FLOP -- 5-11 % faster launches on the
+    // decoder's shapes (tools/gemm_lab_planes.hip -DM16=1; MI355X_MICROARCH.md, clock notes).
+    constexpr int MT = BM / 32;            // 16-row tiles per wave along M
+    constexpr int MI = BM / 64;            // 32-row tiles per wave along M (32x32x16 path)
+    f32x16 acc32[MI][2], accx32[MI][2];      // 32x32x16 path (!M16); the unused set is dead code
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc32[i][j][r] = 0.f; accx32[i][j][r] = 0.f; }
 
-    // fragment of v_mfma_f32_32x32x16_f16: lane (r = lane&31, h = lane>>5) holds k = 8h .. 8h+7 of a 16-wide k block
-    const int fr = lane & 31, fh = lane >> 5, f8 = (fr >> 1) & 7;
+    const int fr32 = lane & 31, fh32 = lane >> 5, f832 = (fr32 >> 1) & 7;
+    f32x4 acc[MT][4], accx[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = acc[i][j]; }
+
+    // operand fragment: lane (r = lane&15, q = lane>>4) holds k = 8q .. 8q+7 of row r -- head chunk q, residual chunk 4 + q
+    const int fr = lane & 15, fq = lane >> 4, f8 = (fr >> 1) & 7;
     const int nk = Kp / GEMM_BK;
-    auto compute = [&](const char* stage) {
+    auto compute16 = [&](const char* stage) {
         const char* sa = stage + (wm * (BM / 2) + fr) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
+        const int sh = (fq ^ f8) * 16, sl = ((4 + fq) ^ f8) * 16;      // (row >> 1) & 7 == (fr >> 1) & 7: tile bases are multiples of 16
+        f16x8 ah[MT], al[MT], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sh);
+            if constexpr (!ONE) al[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sl);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sh);
+            if constexpr (!ONE) bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sl);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!ONE) {
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto compute32 = [&](const char* stage) {
+        const char* sa = stage + (wm * (BM / 2) + fr32) * 128;
+        const char* sw = stage + BM * 128 + (wn * 64 + fr32) * 128;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const int sh = ((2 * kb + fh) ^ f8) * 16, sl = ((4 + 2 * kb + fh) ^ f8) * 16;
+            const int sh = ((2 * kb + fh32) ^ f832) * 16, sl = ((4 + 2 * kb + fh32) ^ f832) * 16;
             f16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -163,13 +201,14 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if constexpr (!ONE) {
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                        accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx32[i][j], 0, 0, 0);
+                        accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx32[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc32[i][j], 0, 0, 0);
                 }
         }
     };
+    auto compute = [&](const char* stage) { if constexpr (M16) compute16(stage); else compute32(stage); };
     setup_run();
     if constexpr (NST == 2) {
         issue(0);
@@ -244,23 +283,35 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 
     // ---- epilogue: park the wave's tile in LDS, re-read it as rows of float4 (16 lanes per row)
     float* Cw = reinterpret_cast<float*>(lds) + wave * ((BM / 2) * P16_CS);
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * P16_CS + j * 32 + fr] = acc[i][j][r] + accx[i][j][r] * (1.0f / F16_RES_SCALE);
+            for (int r = 0; r < 4; ++r)    // D of 16x16x32: lane (col = lane&15, row block lane>>4), register r = row 4 (lane>>4) + r
+                Cw[(i * 16 + 4 * fq + r) * P16_CS + j * 16 + fr] = acc[i][j][r] + accx[i][j][r] * (1.0f / F16_RES_SCALE);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh32) * P16_CS + j * 32 + fr32] = acc32[i][j][r] + accx32[i][j][r] * (1.0f / F16_RES_SCALE);
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
     __builtin_amdgcn_wave_barrier();
 
     gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane);
 }
 
-template <int BM, bool LN, int NST, bool ONE>
-static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
+// MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
+// at most one workgroup per CU are latency-bound and lose 4 % with the longer 16x16 issue sequence; B <= 8 serving shapes).  MTTS_P16_MFMA=16 / 32 forces one shape (A/B runs).
+template <int BM, bool LN, int NST, bool ONE, bool M16>
+static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST, ONE>;
+    auto kern = gemm_p16_kernel<BM, LN, NST, ONE, M16>;
     constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -271,6 +322,13 @@ static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int BM, bool LN, int NST, bool ONE>
+static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
+    static const int shape = [] { const char* e = getenv("MTTS_P16_MFMA"); return e ? atoi(e) : 0; }();
+    const bool m16 = shape == 16 || (shape == 0 && NST != 4);
+    return m16 ? launch_p16_shape<BM, LN, NST, ONE, true>(a, s) : launch_p16_shape<BM, LN, NST, ONE, false>(a, s);
 }
 
 template <int BM, bool LN, int NST = 2>

@@ -110,7 +110,7 @@ class MatchaTTSInfer(nn.Module):
         ``per_request_padding``: the reference derives the padded length, and with it the GroupNorm statistics, the
         attention key set and the noise shape, from the longest utterance of the call, so a request's mel depends on what
         it is batched with.  With this flag every utterance is padded (logically) to its OWN length: each row of a ragged
-        batch equals the batch-of-one result for that request (what a dynamic batcher in front of the reference's
+        batch equals the batch-of-one result for that request to rounding (what a dynamic batcher in front of the reference's
         one-request-at-a-time server needs); one extra host read of the B fine lengths."""
         hip = self._rt.ready()
         dev = x.device

@@ -288,7 +288,8 @@ def test_per_request_padding_equals_batch_of_one(which, lengths, solver, steps, 
         alone = model.synthesise(x[b:b + 1, :n].to(dev), x_len[b:b + 1].to(dev), steps, speaker=spk[b:b + 1].to(dev))
         t = int(alone["mel_lengths"][0])
         assert int(batched["mel_lengths"][b]) == t
-        assert maxabs(batched["mel"][b, :, :t], alone["mel"][0, :, :t]) < 1e-5, f"utterance {b}"
+        # same arithmetic; only the summation order differs where the two grids pick different tile / MFMA shapes
+        assert maxabs(batched["mel"][b, :, :t], alone["mel"][0, :, :t]) < 5e-5, f"utterance {b}"
         worst_default = max(worst_default, maxabs(default["mel"][b, :, :t], alone["mel"][0, :, :t]))
     assert worst_default > 1e-3        # the reference-faithful batch really does differ for the shorter utterances
 
