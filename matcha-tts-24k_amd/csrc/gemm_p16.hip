@@ -209,31 +209,33 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         }
     };
     auto compute = [&](const char* stage) { if constexpr (M16) compute16(stage); else compute32(stage); };
+    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; called right after the
+    // first tile requests so that their loads overlap the tiles' flight
+    auto ln_stats = [&]() {
+        if (LN) {
+            if (tid < BM) {
+                const int row = min(m0 + tid, M - 1);
+                float mean, rstd;
+                if (p.a_part) {
+                    const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
+                    float sm = 0.f, m2 = 0.f;
+                    for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                    mean = sm / (float)p.a_nparts;
+                    for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                    rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
+                } else {
+                    mean = p.a_mean[row];
+                    rstd = p.a_rstd[row];
+                }
+                srow[tid] = mean;
+                srow[BM + tid] = rstd;
+            }
+        }
+    };
     setup_run();
     if constexpr (NST == 2) {
         issue(0);
-    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
-    // the first tile's flight
-    if (LN) {
-        if (tid < BM) {
-            const int row = min(m0 + tid, M - 1);
-            float mean, rstd;
-            if (p.a_part) {
-                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
-                float sm = 0.f, m2 = 0.f;
-                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
-                mean = sm / (float)p.a_nparts;
-                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
-                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
-            } else {
-                mean = p.a_mean[row];
-                rstd = p.a_rstd[row];
-            }
-            srow[tid] = mean;
-            srow[BM + tid] = rstd;
-        }
-    }
-
+        ln_stats();
         __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
@@ -245,28 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         constexpr int D = NST - 1;             // tiles in flight: the one about to be computed + D-1 behind it
         constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
         for (int t = 0; t < D && t < nk; ++t) issue(t);
-    // ---- LayerNorm row statistics (threads 0..BM-1, one row each), parked in LDS for the epilogue; their loads overlap
-    // the first tile's flight
-    if (LN) {
-        if (tid < BM) {
-            const int row = min(m0 + tid, M - 1);
-            float mean, rstd;
-            if (p.a_part) {
-                const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
-                float sm = 0.f, m2 = 0.f;
-                for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
-                mean = sm / (float)p.a_nparts;
-                for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
-                rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
-            } else {
-                mean = p.a_mean[row];
-                rstd = p.a_rstd[row];
-            }
-            srow[tid] = mean;
-            srow[BM + tid] = rstd;
-        }
-    }
-
+        ln_stats();
         int st = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // Tile kt has landed for this wave once at most the D-1 younger tiles are outstanding (the ring's tail just
