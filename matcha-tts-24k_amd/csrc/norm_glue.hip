@@ -143,11 +143,26 @@ __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int
         return;
     }
 
+    // A thread's share of the chunk (<= KEEP rows of 4 channels) stays in registers between the two passes: one trip to
+    // memory, every load in flight at once, and still the exact two-pass (mean, then squared deviations) arithmetic.
+    constexpr int KEEP = 16;
+    const bool in_regs = (chunk_rows + RT - 1) / RT <= KEEP;       // block-uniform
+    f32x4 keep[KEEP];
     float s = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int r = ry + i * RT;
+            keep[i] = r < rows ? *reinterpret_cast<const f32x4*>(base + (size_t)r * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) s += (keep[i][0] + keep[i][1]) + (keep[i][2] + keep[i][3]);
+    } else {
 #pragma unroll 4
-    for (int r = ry; r < rows; r += RT) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+        for (int r = ry; r < rows; r += RT) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
     }
     red[tid] = s;
     __syncthreads();
@@ -160,10 +175,20 @@ __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int
     __syncthreads();
     const float mu = gmean[c4 / cpg4];
     float q = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            if (ry + i * RT < rows) {
+                const f32x4 d = keep[i] - mu;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int r = ry; r < rows; r += RT) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(base + (size_t)r * C) - mu;
-        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        for (int r = ry; r < rows; r += RT) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(base + (size_t)r * C) - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
     }
     red[tid] = q;
     __syncthreads();
