@@ -19,6 +19,7 @@
 // probabilities never leave registers, and the per-query rescale is a lane-uniform multiply of the O^T accumulators.
 // Head dims below 64 (encoder: 48) are zero-padded to 64 in the staged tiles.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mtts {
 
@@ -343,7 +344,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const int b128 = (a.T + 127) / 128, b64 = (a.T + 63) / 64;
     const long blocks128 = (long)b128 * a.H * a.B;
     const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
-    if (blocks128 >= 768 && waste128 < 0.1) {
+    static const int env_nw = [] { const char* e = getenv("MTTS_ATTN_NW"); return e ? atoi(e) : 0; }();     // A/B runs only
+    const bool use128 = env_nw == 4 || (env_nw == 0 && blocks128 >= 768 && waste128 < 0.1);
+    if (use128) {
         if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
