@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace mtts {
 
@@ -131,13 +132,18 @@ struct LayerNormArgs {
 hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
 
 // GroupNorm statistics over (C/G channels x T frames) of y [B,T,C]: partial (mean, M2) per chunk of GN_CHUNK rows.
-// The chunk height adapts to the batch: 32 rows when that already gives >= 512 workgroups, down to 8 rows for small batches
+// The chunk height adapts to the batch: 32 rows when that already gives >= 2048 workgroups (192-thread workgroups of a pure
+// stream need ~10 per CU to keep HBM busy: 4.3 -> 4.1 ms of streaming kernels per step at B = 32), down to 8 rows otherwise
 // (B = 1, T = 640: 80 workgroups of 4 row passes instead of 20 of 16 -- these kernels are latency-bound there).
 constexpr int GN_CHUNK = 32;       // largest chunk
 constexpr int GN_CHUNK_MIN = 8;
+static inline int gn_min_blocks() {
+    static const int v = [] { const char* e = getenv("MTTS_GN_BLOCKS"); return e ? atoi(e) : 2048; }();     // env: A/B runs only
+    return v;
+}
 static inline int gn_chunk_rows(int B, int T) {
     int rows = GN_CHUNK;
-    while (rows > GN_CHUNK_MIN && (long)B * ((T + rows - 1) / rows) < 512) rows >>= 1;
+    while (rows > GN_CHUNK_MIN && (long)B * ((T + rows - 1) / rows) < gn_min_blocks()) rows >>= 1;
     return rows;
 }
 static inline int gn_chunks(int B, int T) { const int r = gn_chunk_rows(B, T); return (T + r - 1) / r; }
