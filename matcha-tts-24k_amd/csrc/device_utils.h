@@ -14,22 +14,20 @@ __device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
     l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
 }
 
-// sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 and the two minimax kernels on
-// [-pi/4, pi/4]; the quadrant only selects which kernel is squared, so no sign handling.  ~1 ulp of sinf for |y| < 1e4
-// (arguments here are O(10)), about a third of the instructions of the library sinf.
+// sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 to r in [-pi/4, pi/4] and the minimax sine
+// kernel; in odd quadrants sin(y)^2 = cos(r)^2 = 1 - sin(r)^2, so one polynomial serves both (sin(r)^2 <= 1/2: the
+// subtraction is benign).  ~1 ulp of sinf(y)^2 for |y| < 1e4 (arguments here are O(10)), a quarter of the library sinf.
 __device__ __forceinline__ float sin_sq(float y) {
     const float n = rintf(y * 0.63661977236758134308f);
     float r = fmaf(n, -1.5707962513e+00f, y);       // pi/2 split: hi, mid, lo
     r = fmaf(n, -7.5497894159e-08f, r);
     r = fmaf(n, -5.3903029534e-15f, r);
     const float z = r * r;
-    // sin(r) = r + r*z*(S1 + z*(S2 + z*(S3 + z*S4)));  cos(r) = 1 - z/2 + z*z*(C1 + z*(C2 + z*C3))
+    // sin(r) = r + r*z*(S1 + z*(S2 + z*(S3 + z*S4)))
     const float sp = fmaf(z, fmaf(z, fmaf(z, 2.7183114939e-06f, -1.9839334836e-04f), 8.3333298564e-03f), -1.6666665459e-01f);
     const float sn = fmaf(r * z, sp, r);
-    const float cp = fmaf(z, fmaf(z, -1.3887316255e-03f, 4.1666645683e-02f) + z * z * 2.4390448928e-05f, -0.5f);
-    const float cs = fmaf(z, cp, 1.0f);
-    const float v = (((int)n) & 1) ? cs : sn;
-    return v * v;
+    const float s2 = sn * sn;
+    return (((int)n) & 1) ? 1.0f - s2 : s2;
 }
 
 __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
