@@ -114,10 +114,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event pass (roofline = null)")
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default 32 = BASELINE configs[1]; other values are labelled)")
+    ap.add_argument("--with-vocoder", action="store_true",
+                    help="NON-DEFAULT: append the Vocos-24k head (random-init weights) to every step: mel -> waveform (configs[3] style)")
     ap.add_argument("--solver", default=SOLVER)
     ap.add_argument("--n-timesteps", type=int, default=N_STEPS_ODE)
     args = ap.parse_args()
-    default_cfg = (args.batch, args.solver, args.n_timesteps) == (BATCH, SOLVER, N_STEPS_ODE)
+    default_cfg = (args.batch, args.solver, args.n_timesteps) == (BATCH, SOLVER, N_STEPS_ODE) and not args.with_vocoder
     BATCH, SOLVER, N_STEPS_ODE = args.batch, args.solver, args.n_timesteps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,8 +152,14 @@ def main():
     sl = dp.shard_slice(BATCH * world, world, rank)
     x, x_len = x_all[sl].to(dev), len_all[sl].to(dev)
 
+    vocoder = None
+    if args.with_vocoder:
+        vocoder = inference.load_vocoder("vocos", state_dict=synthetic.make_vocos_state_dict(seed=11))
+
     def step():
         mel = model.synthesise(x, x_len, n_timesteps=N_STEPS_ODE, speaker=0)["mel"]
+        if vocoder is not None:
+            vocoder(mel)                     # [B, 256 * T_valid] samples at 24 kHz; the metric stays mel frames
         if world > 1:
             mel = dp.all_gather_mels(mel, world)
         return mel
@@ -225,7 +233,7 @@ def main():
             "value": round(frames / el, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": GEMM_MODES[terms][0], "data": "synthetic",
-            "config": {"workload": ("" if default_cfg else f"NON-DEFAULT batch={BATCH} {SOLVER}/{N_STEPS_ODE} variant of ") +
+            "config": {"workload": ("" if default_cfg else f"NON-DEFAULT batch={BATCH} {SOLVER}/{N_STEPS_ODE}{' + Vocos head' if args.with_vocoder else ''} variant of ") +
                                    "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
                                    "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "
                                    "(reference 2x padding), noise from the device seed-42 generator",
