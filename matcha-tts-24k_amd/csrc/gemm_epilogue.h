@@ -19,6 +19,13 @@ constexpr int GEMM_CS = 68;   // row stride of the parked tile (floats)
 
 template <int V> struct IntC { static constexpr int value = V; };
 
+__device__ __forceinline__ float allreduce64(float v) {     // every lane gets the wave's total
+    v = allreduce16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 // LN: LayerNorm-in-the-epilogue (P16 kernel): srow = [BM means | BM rstds] in LDS, p.wsum = panel row sums.
 template <int BM, bool LN>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
@@ -35,6 +42,35 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         if (p.act == ACT_SNAKE) { s0 = *reinterpret_cast<const f32x4*>(p.p0 + nc); s1 = *reinterpret_cast<const f32x4*>(p.p1 + nc); }
         if (LN) ws4 = *reinterpret_cast<const f32x4*>(p.wsum + nc);
     }
+    // ---- GroupNorm statistics of the output (conv feeding a Block1D): two passes over the parked tile -- the group means of
+    // this wave tile first, then squared deviations inside the main loop -- so no second trip over the tensor is needed.
+    const bool gn = p.gn_stats != nullptr;
+    int gn_rows = 0, gn_gi = 0;
+    float gn_mean[2] = {0.f, 0.f}, gn_n[2] = {0.f, 0.f}, gn_q = 0.f;
+    if (gn) {
+        const int rows_w = BM / 2, row_w0 = m0 + wm * rows_w;             // T_out % rows_w == 0: one batch element per wave tile
+        const int b = min(row_w0 / p.T_out, p.B - 1), t_w0 = row_w0 - b * p.T_out;      // (tail tiles past M: gn_rows = 0 below)
+        const int Tb = p.gn_tlen ? min(p.T_out, p.gn_tlen[b] >> p.gn_tshift) : p.T_out;
+        gn_rows = row_w0 < M ? max(0, min(rows_w, Tb - t_w0)) : 0;
+        const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
+        const int cols0 = min(64, (g0 + 1) * cpg - n0w);
+        gn_gi = (nc / cpg) - g0;                                          // 0 or 1: this lane's group slice (cpg >= 32)
+        gn_n[0] = (float)(gn_rows * cols0);
+        gn_n[1] = (float)(gn_rows * (64 - cols0));
+        float s1 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rl = it * 4 + (lane >> 4);
+            if (rl < gn_rows) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * GEMM_CS + (lane & 15) * 4) + bias4;
+                s1 += (a[0] + a[1]) + (a[2] + a[3]);
+            }
+        }
+        const float t0 = allreduce64(gn_gi == 0 ? s1 : 0.f), t1 = allreduce64(gn_gi == 1 ? s1 : 0.f);
+        gn_mean[0] = gn_n[0] > 0.f ? t0 / gn_n[0] : 0.f;
+        gn_mean[1] = gn_n[1] > 0.f ? t1 / gn_n[1] : 0.f;
+    }
+    const float gn_mu = gn_gi == 0 ? gn_mean[0] : gn_mean[1];
     auto run = [&](auto act_c, auto res_c) {
         constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
         constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows (p.res), 2 a P16 image (p.res16)
@@ -78,6 +114,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                     o = (a - mean * ws4) * rstd + bias4;
                 } else {
                     o = a + bias4;
+                }
+                if (gn && rl < gn_rows) {
+                    const f32x4 d = o - gn_mu;
+                    gn_q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
                 }
                 if constexpr (ACT == 1) {
 #pragma unroll
@@ -134,6 +174,15 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         if (actk == 0) run(IntC<0>{}, IntC<0>{});
         else if (actk == 1) run(IntC<1>{}, IntC<0>{});
         else run(IntC<2>{}, IntC<0>{});
+    }
+    if (gn) {
+        const float q0 = allreduce64(gn_gi == 0 ? gn_q : 0.f), q1 = allreduce64(gn_gi == 1 ? gn_q : 0.f);
+        if (lane == 0 && m0 + wm * (BM / 2) < M) {
+            const int row_wave = (m0 + wm * (BM / 2)) / (BM / 2), col_wave = (n0 + wn * 64) >> 6;
+            float* e = p.gn_stats + ((size_t)(row_wave * (p.N >> 6) + col_wave) * 2) * 4;
+            *reinterpret_cast<f32x4*>(e) = f32x4{gn_n[0], gn_mean[0], q0, 0.f};
+            *reinterpret_cast<f32x4*>(e + 4) = f32x4{gn_n[1], gn_mean[1], q1, 0.f};
+        }
     }
 }
 

@@ -317,6 +317,36 @@ static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
     return a.fast16 ? launch_p16_one<BM, LN, NST, true>(a, s) : launch_p16_one<BM, LN, NST, false>(a, s);
 }
 
+// Block-tile height and pipeline depth for a shape (also what gemm_p16_wave_rows reports to callers that must match it).
+// Height by grid fill, as launch_gemm: 2 resident workgroups per CU for either height (LDS 70 / 49 KB).  Small grids (serving
+// shapes, B <= 8): 64-row tiles on the prefetch ring -- 4 stages at <= 1 workgroup per CU (96 KB of LDS), 3 stages at <= 2
+// (72 KB).  MTTS_P16_RING=0 keeps the two-stage kernel, 2 puts every 64-row grid on the ring; MTTS_GEMM_BM forces a height.
+static int p16_choose(const GemmArgs& a, int& nst) {
+    const int M = a.B * a.T_out;
+    const int nt = (a.N + GEMM_BN - 1) / GEMM_BN;
+    auto fill = [&](int bm) {
+        const int tiles = ((M + bm - 1) / bm) * nt;
+        const int rounds = (tiles + 511) / 512;
+        return (double)tiles / (rounds * 512.0) * ((double)M / (((M + bm - 1) / bm) * bm));
+    };
+    static const int ring_mode = [] { const char* e = getenv("MTTS_P16_RING"); return e ? atoi(e) : 1; }();
+    static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();
+    const int tiles64 = ((M + 63) / 64) * nt;
+    nst = 2;
+    if (ring_mode != 0 && a.force_bm == 0 && tiles64 <= 512) {
+        nst = tiles64 <= 256 ? 4 : 3;
+        return 64;
+    }
+    const int force = a.force_bm ? a.force_bm : env_bm;
+    const bool bm64 = force == 64 || (force == 0 && 0.97 * fill(64) > fill(128));
+    if (bm64 && ring_mode == 2) nst = 3;
+    return bm64 ? 64 : 128;
+}
+int gemm_p16_wave_rows(const GemmArgs& a) {
+    int nst;
+    return p16_choose(a, nst) / 2;
+}
+
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     // shape contract (the kernel indexes without further checks)
     if (!a.a16_0 || !a.w16 || a.terms != 2 || (!a.out && !a.out16) || a.N <= 0 || (a.N & 3) || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0)
@@ -336,28 +366,20 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (a.out16 && ((a.N % 32) || a.ld16 < 2 * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
-    // Block-tile height by grid fill, as launch_gemm: 2 resident workgroups per CU for either height (LDS 70 / 49 KB).
-    const int M = a.B * a.T_out;
-    const int nt = (a.N + GEMM_BN - 1) / GEMM_BN;
-    auto fill = [&](int bm) {
-        const int tiles = ((M + bm - 1) / bm) * nt;
-        const int rounds = (tiles + 511) / 512;
-        return (double)tiles / (rounds * 512.0) * ((double)M / (((M + bm - 1) / bm) * bm));
-    };
-    // Small grids (serving shapes, B <= 8): 64-row tiles on the prefetch ring -- 4 stages at <= 1 workgroup per CU (96 KB
-    // of LDS), 3 stages at <= 2 (72 KB).  MTTS_P16_RING=0 keeps the two-stage kernel (A/B runs).
-    static const int ring_mode = [] { const char* e = getenv("MTTS_P16_RING"); return e ? atoi(e) : 1; }();   // 2: ring for every 64-row grid (A/B)
-    const bool ring_on = ring_mode != 0;
-    const int tiles64 = ((M + 63) / 64) * nt;
-    if (ring_on && a.force_bm == 0 && tiles64 <= 512) {
-        if (tiles64 <= 256) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
-        return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
+    if (a.gn_stats) {
+        const int rows_w = gemm_p16_wave_rows(a);
+        const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
+        if (a.gn_groups <= 0 || (a.N % a.gn_groups) || (a.N / a.gn_groups) < 32 || ((a.N / a.gn_groups) & 3) || (a.N & 63) || !plain ||
+            (a.T_out % rows_w) || a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f || ln)
+            return hipErrorInvalidValue;
     }
-    static const int env_bm = [] { const char* e = getenv("MTTS_GEMM_BM"); return e ? atoi(e) : 0; }();   // A/B runs only
-    const int force = a.force_bm ? a.force_bm : env_bm;
-    const bool bm64 = force == 64 || (force == 0 && 0.97 * fill(64) > fill(128));
-    if (bm64 && ring_mode == 2) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
-    if (bm64) return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
+    int nst = 2;
+    const int bm = p16_choose(a, nst);
+    if (bm == 64) {
+        if (nst == 4) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
+        if (nst == 3) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
+        return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
+    }
     return ln ? launch_p16_variant<128, true>(a, s) : launch_p16_variant<128, false>(a, s);
 }
 

@@ -68,10 +68,19 @@ struct GemmArgs {
     const float* out16_mask = nullptr;// [rows] multiplies the out16 copy only (conv consumers read masked rows; out stays as is)
     const _Float16* res16 = nullptr;  // residual as a P16 image (2^11-scaled residual plane) instead of fp32 rows; N % 32 == 0
     int ldr16 = 0;                    // its row stride in halves; may alias out16 (in-place update of the residual stream)
+    // GroupNorm statistics of the output from the epilogue (conv -> Block1D, P16 kernel): per wave tile (BM/2 rows x 64 columns)
+    // and per group slice inside it (<= 2: needs (N / gn_groups) >= 32) an entry (n, mean, M2, -) at
+    // gn_stats[((row_wave * (N/64) + col_wave) * 2 + slice) * 4]; launch_gn_apply merges them (tile_stats).  Needs plain rows,
+    // T_out % (BM/2) == 0 (gemm_p16_wave_rows), N % 64 == 0 and an epilogue of bias only.
+    float* gn_stats = nullptr;
+    int gn_groups = 0;
+    const int* gn_tlen = nullptr;     // per-utterance frame limits (>> gn_tshift), as the GroupNorm kernels' tlen
+    int gn_tshift = 0;
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
+int gemm_p16_wave_rows(const GemmArgs& a);                          // rows of a wave tile (BM/2) launch_gemm_p16 will use for these shapes
 // fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
                          hipStream_t s);   // channels [C_valid, C) are written as zeros
@@ -166,6 +175,8 @@ struct GnApplyArgs {
     const int* tlen = nullptr;        // [B] per-utterance frame limit (>> tshift) for the statistics; null = T
     int tshift = 0;
     int chunk_rows = 0;               // set by launch_gn_apply (gn_chunk_rows(B, T)), must match the partial pass
+    const float* tile_stats = nullptr;// alternative to `partial`: the entries a P16 GEMM's epilogue left (GemmArgs::gn_stats)
+    int tile_rows = 0;                // rows per wave tile of that GEMM (gemm_p16_wave_rows); T % tile_rows == 0
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);

@@ -379,6 +379,7 @@ struct DecBufs {
     std::vector<float*> bufA, bufB, skip;
     float *Y = nullptr, *Hh = nullptr, *Rr = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
     float *mean = nullptr, *rstd = nullptr, *gnp = nullptr, *lnp = nullptr;
+    float* gns = nullptr;                // GroupNorm tile statistics left by the conv GEMMs' epilogues (P16 decoder)
     _Float16* X16 = nullptr;             // P16 image of the residual stream x (the LayerNorm'd projections' LDS-DMA source)
     // P16 decoder (decoder_eval_p16): every conv / projection input exists as a P16 image, written by its producer
     bool p16 = false;
@@ -443,6 +444,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
         d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, GEMM_BK)));
     }
     d.gnp = ws.f((size_t)B * gn_chunks_max(T) * 8 * 2);
+    d.gns = ws.f((M0 / 32 + 1) * (size_t)((cmax + 63) / 64) * 8);
     d.ldx = round_up(2 * g.n_feats, GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
     d.xmu = ws.f(M0 * d.ldx);
@@ -696,6 +698,15 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     return 0;
 }
 
+// GroupNorm statistics from the conv GEMM's epilogue instead of a gn_partial pass over its output (gemm_epilogue.h): needs
+// whole wave tiles per utterance and groups of >= 32 channels; MTTS_GN_FUSE=0 keeps the separate pass (A/B runs).
+static int gn_fuse_rows(const GemmArgs& a, int C, int G, int T) {
+    static const bool on = [] { const char* e = getenv("MTTS_GN_FUSE"); return !(e && e[0] == '0'); }();
+    if (!on || !a.a16_0 || (C % 64) || (C % G) || (C / G) < 32 || ((C / G) & 3)) return 0;
+    const int rows = gemm_p16_wave_rows(a);
+    return (T % rows) == 0 ? rows : 0;
+}
+
 // ---- P16 decoder: the same network with every GEMM on pre-split operands (gemm_p16.hip).  Each producer writes the P16
 // image its consumers read (already multiplied by the frame mask where the reference masks the input): GroupNorm-apply,
 // the GEMM epilogues, and one conversion pass for the ODE state.  fp32 copies exist only where an fp32 consumer remains
@@ -708,23 +719,29 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     panel_args(c, r.conv1, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a16_0 = in0; a.lda16_0 = 2 * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = 2 * c1; a.c1 = c1;
     a.out = d.Y; a.ldc = C;
+    const int fr1 = gn_fuse_rows(a, C, 8, T);
+    if (fr1) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_tlen = c->d_tlen; a.gn_tshift = lvl; }
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    if (!fr1) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GnApplyArgs g1;
+    if (fr1) { g1.tile_stats = d.gns; g1.tile_rows = fr1; }
     g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.tlen = c->d_tlen; g1.tshift = lvl;
     g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
     LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
+    const int fr2 = gn_fuse_rows(b, C, 8, T);
+    if (fr2) { b.gn_stats = d.gns; b.gn_groups = 8; b.gn_tlen = c->d_tlen; b.gn_tshift = lvl; }
     RET_IF(run_gemm(c, b, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    if (!fr2) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
     rc.out = d.Rr; rc.ldc = C;
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
+    if (fr2) { g2.tile_stats = d.gns; g2.tile_rows = fr2; }
     g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
     g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;          // no fp32 copy: x lives on as its image only
     (void)out;
@@ -812,9 +829,12 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     GemmArgs a;
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a16_0 = cur; a.lda16_0 = 2 * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
+    const int frf = gn_fuse_rows(a, C0, 8, T);
+    if (frf) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_tlen = c->d_tlen; a.gn_tshift = 0; }
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
+    if (!frf) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
     GnApplyArgs ga;
+    if (frf) { ga.tile_stats = d.gns; ga.tile_rows = frf; }
     ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.tlen = c->d_tlen;
     ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
     LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));

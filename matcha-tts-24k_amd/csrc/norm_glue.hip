@@ -243,7 +243,23 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
         while (L > 1 && L * p.G > nth) L >>= 1;
         const int g = tid / L, j = tid - g * L;
         float n = 0.f, mean = 0.f, m2 = 0.f;
-        if (g < p.G) {
+        if (g < p.G && p.tile_stats) {
+            // entries left by the producing GEMM's epilogue: per wave tile (tile_rows rows x 64 columns) and group slice
+            const int ncw = p.C >> 6, nrw = p.T / p.tile_rows;
+            const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
+            for (int k = j; k < nrw * nw; k += L) {
+                const int rw = k / nw, w = w_lo + (k - rw * nw);
+                const int slice = g - (w * 64) / cpg;
+                const float* q = p.tile_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + slice) * 4;
+                const float nb = q[0];
+                if (nb <= 0.f) continue;
+                const float delta = q[1] - mean;
+                const float nt = n + nb;
+                mean += delta * (nb / nt);
+                m2 += q[2] + delta * delta * (n * nb / nt);
+                n = nt;
+            }
+        } else if (g < p.G) {
             const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;
             for (int k = j; k < nchunks; k += L) {
                 const int rows_k = min(p.chunk_rows, Tb - k * p.chunk_rows);
@@ -340,12 +356,13 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
 }
 
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
-    if (!a.y || !a.partial || !a.gamma || !a.beta || !a.mask || (!a.out && !a.out16) || a.B <= 0 || a.T <= 0 || !gn_shape_ok(a.C, a.G) ||
+    if (!a.y || (!a.partial && !a.tile_stats) || !a.gamma || !a.beta || !a.mask || (!a.out && !a.out16) || a.B <= 0 || a.T <= 0 || !gn_shape_ok(a.C, a.G) ||
         (a.res && (a.ldr & 3)))
         return hipErrorInvalidValue;
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
     if (a.out16 && ((a.C & 31) || a.ld16 < 2 * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
+    if (a.tile_stats && (a.tile_rows <= 0 || (a.T % a.tile_rows) || (a.C & 63) || (a.C / a.G) < 32)) return hipErrorInvalidValue;
     GnApplyArgs b = a;
     b.chunk_rows = gn_chunk_rows(a.B, a.T);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.B, a.T), a.B), gn_block(a.C), 0, s, b);
