@@ -30,6 +30,14 @@ __device__ __forceinline__ float sin_sq(float y) {
     return (((int)n) & 1) ? 1.0f - s2 : s2;
 }
 
+// Mish(x) = x tanh(softplus(x)) = x w / (w + 2), w = e^x (e^x + 2)   (reference decoder.py:32-45, nn.Mish)
+__device__ __forceinline__ float mish_f(float x) {
+    if (x > 20.f) return x;
+    const float n = expf(x);
+    const float w = n * (n + 2.f);
+    return x * (w / (w + 2.f));
+}
+
 __device__ __forceinline__ float act_apply(float c, int act, float p0, float p1) {
     switch (act) {
         case ACT_RELU: return c > 0.f ? c : 0.f;

@@ -29,7 +29,7 @@ __device__ __forceinline__ float allreduce64(float v) {     // every lane gets t
 // LN: LayerNorm-in-the-epilogue (P16 kernel): srow = [BM means | BM rstds] in LDS, p.wsum = panel row sums.
 template <int BM, bool LN>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
-                                                   int M, int m0, int n0, int wm, int wn, int lane) {
+                                                   int M, int m0, int n0, int wm, int wn, int lane, const float* __restrict__ gstat = nullptr) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
     constexpr int NIT = BM / 8;                              // rows per lane: 4 rows per pass x NIT passes
@@ -71,16 +71,26 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         gn_mean[1] = gn_n[1] > 0.f ? t1 / gn_n[1] : 0.f;
     }
     const float gn_mu = gn_gi == 0 ? gn_mean[0] : gn_mean[1];
+    // Block1D tail: this lane's group statistics (merged in the prologue into gstat = [mean x 4 | rstd x 4]) and affine
+    float gnr_mu = 0.f, gnr_rs = 1.f;
+    f32x4 gnr_gm = {0.f, 0.f, 0.f, 0.f}, gnr_bt = gnr_gm;
+    if (p.gnr_y && col_ok) {
+        const int cpg = p.N / p.gnr_groups, gl = nc / cpg - n0 / cpg;
+        gnr_mu = gstat[gl];
+        gnr_rs = gstat[4 + gl];
+        gnr_gm = *reinterpret_cast<const f32x4*>(p.gnr_gamma + nc);
+        gnr_bt = *reinterpret_cast<const f32x4*>(p.gnr_beta + nc);
+    }
     auto run = [&](auto act_c, auto res_c) {
         constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
-        constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows (p.res), 2 a P16 image (p.res16)
-        constexpr bool RES = RESK == 1;
+        constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows (p.res), 2 a P16 image (p.res16), 3 Block1D tail (gnr_*)
+        constexpr bool RES = RESK == 1 || RESK == 3;          // both prefetch fp32 rows
         // chunks of U passes (4 U rows of the tile): all of a chunk's residual / mask loads are in flight together
         constexpr int U = 4;
         for (int c0 = 0; c0 < NIT; c0 += U) {
             int orow[U];
             bool ok[U];
-            float om[U], om16[U];
+            float om[U], om16[U], gmk[RESK == 3 ? U : 1];
             f32x4 rres[RES ? U : 1];
             f16x4 r16h[RESK == 2 ? U : 1], r16l[RESK == 2 ? U : 1];
 #pragma unroll
@@ -96,7 +106,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 orow[u] = r;
                 om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
                 om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
-                if constexpr (RES) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
+                if constexpr (RESK == 1) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
+                if constexpr (RESK == 3) {
+                    rres[u] = *reinterpret_cast<const f32x4*>(p.gnr_y + (size_t)r * p.N + (col_ok ? nc : 0));
+                    gmk[u] = p.gnr_mask[r];
+                }
                 if constexpr (RESK == 2) {
                     const int ncl = col_ok ? nc : 0;
                     const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
@@ -128,7 +142,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 }
                 o *= om[u];
                 if (p.out_scale != 1.0f) o *= p.out_scale;
-                if constexpr (RES) o += rres[u];
+                if constexpr (RESK == 1) o += rres[u];
+                if constexpr (RESK == 3) {           // Mish(GroupNorm(y)) * mask, same operation order as gn_apply_kernel
+                    f32x4 v = ((rres[u] - gnr_mu) * gnr_rs) * gnr_gm + gnr_bt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mish_f(v[e]) * gmk[u];
+                    o += v;
+                }
                 if constexpr (RESK == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += (float)r16h[u][e] + (float)r16l[u][e] * (1.0f / F16_RES_SCALE);
@@ -162,7 +182,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         }
     };
     const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
-    if (p.res16) {             // the residual stream kept only as a P16 image (decoder transformer blocks)
+    if (p.gnr_y) {             // ResNet output = residual conv + Block1D tail
+        run(IntC<0>{}, IntC<3>{});
+    } else if (p.res16) {      // the residual stream kept only as a P16 image (decoder transformer blocks)
         if (actk == 0) run(IntC<0>{}, IntC<2>{});
         else if (actk == 1) run(IntC<1>{}, IntC<2>{});
         else run(IntC<2>{}, IntC<2>{});

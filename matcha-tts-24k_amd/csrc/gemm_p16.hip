@@ -232,10 +232,50 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
             }
         }
     };
+    // ---- Block1D tail (gnr_*): wave 0 merges the producing conv's tile entries for the <= 4 groups under this workgroup's 128
+    // columns (16 lanes per group, Chan merge, fixed order) into gstat = [mean x 4 | rstd x 4], parked where srow would be.
+    auto gnr_prologue = [&]() {
+        if (p.gnr_y && tid < 64) {
+            const int cpg = p.N / p.gnr_groups, gl = tid >> 4, j = tid & 15, g = n0 / cpg + gl;
+            const bool live = g < p.gnr_groups && g * cpg < min(p.N, n0 + GEMM_BN);
+            const int b = min(m0 / p.T_out, p.B - 1);
+            const int ncw = p.N >> 6, nrw = p.T_out / p.gnr_tile_rows;
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            if (live) {
+                const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
+                for (int k = j; k < nrw * nw; k += 16) {
+                    const int rw = k / nw, w = w_lo + (k - rw * nw);
+                    const float* q = p.gnr_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4;
+                    const float nb = q[0];
+                    if (nb <= 0.f) continue;
+                    const float delta = q[1] - mean, nt = n + nb;
+                    mean += delta * (nb / nt);
+                    m2 += q[2] + delta * delta * (n * nb / nt);
+                    n = nt;
+                }
+            }
+            for (int off = 1; off < 16; off <<= 1) {
+                const float n2 = __shfl_xor(n, off), mean2 = __shfl_xor(mean, off), m22 = __shfl_xor(m2, off);
+                const float nt = n + n2;
+                if (nt > 0.f) {
+                    const float delta = mean2 - mean, w2 = n2 / nt;
+                    const float merged = (j & off) ? mean2 + (mean - mean2) * (n / nt) : mean + delta * w2;
+                    m2 = m2 + m22 + delta * delta * (n * w2);
+                    mean = merged;
+                    n = nt;
+                }
+            }
+            if (j == 0) {
+                srow[gl] = mean;
+                srow[4 + gl] = n > 0.f ? 1.0f / sqrtf(m2 / n + p.gnr_eps) : 0.f;
+            }
+        }
+    };
     setup_run();
     if constexpr (NST == 2) {
         issue(0);
         ln_stats();
+        gnr_prologue();
         __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
@@ -248,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
         for (int t = 0; t < D && t < nk; ++t) issue(t);
         ln_stats();
+        gnr_prologue();
         int st = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // Tile kt has landed for this wave once at most the D-1 younger tiles are outstanding (the ring's tail just
@@ -284,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
     __builtin_amdgcn_wave_barrier();
 
-    gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane);
+    gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);     // (gstat shares srow's slot: never both)
 }
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
@@ -375,6 +416,13 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     }
     int nst = 2;
     const int bm = p16_choose(a, nst);
+    if (a.gnr_y) {
+        const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
+        if (!a.gnr_stats || !a.gnr_gamma || !a.gnr_beta || !a.gnr_mask || a.gnr_groups <= 0 || a.gnr_tile_rows <= 0 || (a.N % a.gnr_groups) ||
+            (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 3) || (a.N & 63) || !plain || (a.T_out % bm) || (a.T_out % a.gnr_tile_rows) || ln ||
+            a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f)
+            return hipErrorInvalidValue;
+    }
     if (bm == 64) {
         if (nst == 4) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
         if (nst == 3) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);

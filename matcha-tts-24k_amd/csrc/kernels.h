@@ -76,6 +76,15 @@ struct GemmArgs {
     int gn_groups = 0;
     const int* gn_tlen = nullptr;     // per-utterance frame limits (>> gn_tshift), as the GroupNorm kernels' tlen
     int gn_tshift = 0;
+    // Block1D tail in the epilogue (ResNet output, P16 kernel): c += Mish(GroupNorm(y)[row][n]) * gnr_mask[row], where y is the
+    // second conv's fp32 output and its statistics are the tile entries that conv's epilogue left (gn_stats there): this GEMM
+    // is the ResNet's 1x1 residual conv, so the sum is the ResNet output (reference decoder.py:58-63) and no gn_apply pass or
+    // residual round trip remains.  Needs T_out % BM == 0 (a workgroup's rows in one utterance) and N / gnr_groups >= 32.
+    const float* gnr_y = nullptr;     // [M][N] fp32 rows (ld = N)
+    const float* gnr_stats = nullptr; // entries as GemmArgs::gn_stats of the producing conv
+    int gnr_tile_rows = 0, gnr_groups = 0;
+    const float* gnr_gamma = nullptr; const float* gnr_beta = nullptr; const float* gnr_mask = nullptr;
+    float gnr_eps = 1e-5f;
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);

@@ -738,13 +738,23 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
+    (void)out;                                                        // no fp32 copy: x lives on as its image only
+    static const bool tail_on = [] { const char* e = getenv("MTTS_GN_TAIL"); return !(e && e[0] == '0'); }();   // A/B runs
+    if (tail_on && fr2 && (T % (2 * gemm_p16_wave_rows(rc))) == 0) {
+        // The 1x1 residual conv finishes the block: its epilogue adds Mish(GroupNorm(conv2 output)) * mask from the tile
+        // statistics conv2 left, and writes x's image + LayerNorm moments -- no gn_apply pass, no residual round trip.
+        rc.gnr_y = d.Y; rc.gnr_stats = d.gns; rc.gnr_tile_rows = fr2; rc.gnr_groups = 8;
+        rc.gnr_gamma = W(c, r.gn2_g.off); rc.gnr_beta = W(c, r.gn2_b.off); rc.gnr_mask = mask;
+        rc.out16 = d.X16; rc.ld16 = 2 * C; rc.stats_out = d.lnp;
+        RET_IF(run_gemm(c, rc, s));
+        return 0;
+    }
     rc.out = d.Rr; rc.ldc = C;
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
     if (fr2) { g2.tile_stats = d.gns; g2.tile_rows = fr2; }
     g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
-    g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;          // no fp32 copy: x lives on as its image only
-    (void)out;
+    g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;
     g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
     LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
     return 0;

@@ -2,6 +2,7 @@
 // kernels over channels-last activations [rows, C]: float4 per lane, rows assigned to waves, no atomics, and every
 // reduction has a fixed order (results are bitwise reproducible run to run).
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace mtts {
 
@@ -15,12 +16,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Mish(x) = x * tanh(softplus(x)), softplus threshold 20 (torch.nn.Mish; reference decoder.py:40,51).
 // tanh(log(1+e^x)) = (n^2 + 2n) / (n^2 + 2n + 2) with n = e^x: no cancellation for negative x.
-__device__ __forceinline__ float mish_f(float x) {
-    if (x > 20.f) return x;
-    const float n = expf(x);
-    const float w = n * (n + 2.f);
-    return x * (w / (w + 2.f));
-}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
