@@ -294,6 +294,28 @@ def test_per_request_padding_equals_batch_of_one(which, lengths, solver, steps, 
     assert worst_default > 1e-3        # the reference-faithful batch really does differ for the shorter utterances
 
 
+@pytest.mark.parametrize("channels,n_blocks,heads", [((128, 128), 1, 2), ((256, 256), 2, 3), ((128, 256), 1, 2)])
+def test_small_p16_decoders_vs_oracle(channels, n_blocks, heads, hparams, synthetic, oracle, dev):
+    """Narrow estimators that still qualify for the P16 flow (widths multiples of 64, 64-wide heads): groups of 16 / 32
+    channels (GroupNorm statistics from the separate pass / from the conv epilogue with two groups per 64 columns), single-tile
+    GEMMs, unequal level widths -- ragged batch, midpoint, against the oracle run here."""
+    import dataclasses
+    hp = hparams.tiny(n_spks=2)
+    hp = dataclasses.replace(hp, decoder=dataclasses.replace(hp.decoder, channels=channels, attention_head_dim=64,
+                                                             n_blocks=n_blocks, num_mid_blocks=1, num_heads=heads))
+    sd = synthetic.make_state_dict(hp, seed=21)
+    model = make_model(hp, sd, dev)
+    lengths = [14, 9, 3]
+    x, x_len, spk = synthetic.make_inputs(hp, 3, max(lengths), seed=8, lengths=lengths)
+    t_pad = 2 * ((5 * max(lengths) + 1) // 2)
+    z = synthetic.cpu_noise((3, hp.n_feats, t_pad)).to(dev)
+    model.decoder.solver = "midpoint"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=spk.to(dev), z=z)
+    ref = oracle.synthesise(sd, hp, x, x_len, 2, speaker=spk, solver="midpoint", z=z.cpu())
+    assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"])
+    assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
+
+
 def test_config2_batch32_properties(prod, synthetic, dev):
     """BASELINE config #2 (B=32, Tx=128, euler/10) at full size: size-independent checks.
     All utterances of a batch are independent (per-sample norms and attention), so row b of the batched result must
