@@ -35,8 +35,8 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense
 # GEMM arithmetic modes (csrc/gemm_f32.hip): MFMA products executed per fp32-equivalent multiply-accumulate
 GEMM_MODES = {0: ("f32", "v_mfma_f32_32x32x2_f32 on fp32 operands", 1, PEAK_F32_MFMA_TFLOPS),
               1: ("f16 operands, fp32 accumulate (OPT-IN reduced precision, MTTS_GEMM_TERMS=1: not the headline arithmetic)",
-                  "v_mfma_f32_32x32x16_f16, 1 product per MAC", 1, PEAK_16BIT_MFMA_TFLOPS),
-              2: ("f32 via 2-term f16 split (fp32 accumulate)", "v_mfma_f32_32x32x16_f16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS),
+                  "v_mfma_f32_16x16x32_f16 / 32x32x16_f16, 1 product per MAC", 1, PEAK_16BIT_MFMA_TFLOPS),
+              2: ("f32 via 2-term f16 split (fp32 accumulate)", "v_mfma_f32_16x16x32_f16 / 32x32x16_f16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS),
               6: ("f32 via 3-term bf16 split (fp32 accumulate)", "v_mfma_f32_32x32x16_bf16, 6 products per MAC", 6, PEAK_16BIT_MFMA_TFLOPS),
               3: ("f32 via 2-term bf16 split (fp32 accumulate, ~2^-17 per product)", "v_mfma_f32_32x32x16_bf16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS)}
 BATCH, N_TOKENS, N_STEPS_ODE, SOLVER = 32, 128, 10, "euler"

@@ -97,10 +97,13 @@ hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lsca
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
 }
-// compulsory HBM bytes of one launch: every input row, weight, residual and output element once
+// compulsory HBM bytes of one launch: every input row, weight, residual and output element once (a P16 image has the bytes of
+// the fp32 tensor it stands for; an fp32 and a P16 copy of the output count separately, as does the Block1D-tail input)
 static inline double gemm_bytes(const GemmArgs& a) {
     const double M = double(a.B) * a.T_out, Min = double(a.B) * a.T_in;
-    return 4.0 * (Min * (a.c0 + a.c1) + double(a.N) * a.ntaps * (a.c0 + a.c1) + M * a.N * (a.res ? 2.0 : 1.0));
+    const double outs = (a.out ? 1.0 : 0.0) + (a.out16 ? 1.0 : 0.0);
+    const double ins = ((a.res || a.res16) ? 1.0 : 0.0) + (a.gnr_y ? 1.0 : 0.0);
+    return 4.0 * (Min * (a.c0 + a.c1) + double(a.N) * a.ntaps * (a.c0 + a.c1) + M * a.N * (outs + ins));
 }
 
 // Pack a torch weight into the GEMM panel layout [Np][ntaps*ktap] (host side).
