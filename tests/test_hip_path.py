@@ -316,6 +316,26 @@ def test_small_p16_decoders_vs_oracle(channels, n_blocks, heads, hparams, synthe
     assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
 
 
+@pytest.mark.parametrize("lengths", [[27], [13, 9], [31, 30, 29, 5, 1]])
+def test_prod_odd_lengths_p16_vs_fp32_operand_path(lengths, prod, synthetic, dev, monkeypatch):
+    """Padded lengths that are not multiples of the wave-tile height (T = 136, 66, 156: the GroupNorm statistics fall back from
+    the conv epilogue to the separate pass, tail tiles are partly empty): the P16 flow must agree with the fp32-operand flow
+    (MTTS_P16=0, independent kernels for every GEMM / attention / GroupNorm step) to rounding."""
+    hp, sd, model = prod
+    B = len(lengths)
+    x, x_len, _ = synthetic.make_inputs(hp, B, max(lengths), seed=31, lengths=lengths)
+    monkeypatch.setenv("MTTS_P16", "0")
+    plain = make_model(hp, sd, dev)
+    plain.decoder.solver = "euler"
+    ref = plain.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0)
+    monkeypatch.delenv("MTTS_P16")
+    model.decoder.solver = "euler"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0)
+    assert torch.equal(out["mel_lengths"], ref["mel_lengths"])
+    assert torch.isfinite(out["mel"]).all()
+    assert maxabs(out["mel"], ref["mel"]) < 2e-4
+
+
 def test_config2_batch32_properties(prod, synthetic, dev):
     """BASELINE config #2 (B=32, Tx=128, euler/10) at full size: size-independent checks.
     All utterances of a batch are independent (per-sample norms and attention), so row b of the batched result must
