@@ -219,9 +219,20 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                 if (p.a_part) {
                     const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
                     float sm = 0.f, m2 = 0.f;
-                    for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
-                    mean = sm / (float)p.a_nparts;
-                    for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                    if (p.a_nparts == 6) {         // width 384: the row's 12 floats as three 16-byte loads, one round trip
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(q), v1 = *reinterpret_cast<const f32x4*>(q + 4),
+                                    v2 = *reinterpret_cast<const f32x4*>(q + 8);
+                        const float mk[6] = {v0[0], v0[2], v1[0], v1[2], v2[0], v2[2]};
+                        sm = ((mk[0] + mk[1]) + (mk[2] + mk[3])) + (mk[4] + mk[5]);
+                        m2 = ((v0[1] + v0[3]) + (v1[1] + v1[3])) + (v2[1] + v2[3]);
+                        mean = sm / 6.0f;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { const float d = mk[k] - mean; m2 += 64.0f * (d * d); }
+                    } else {
+                        for (int k = 0; k < p.a_nparts; ++k) { sm += q[2 * k]; m2 += q[2 * k + 1]; }
+                        mean = sm / (float)p.a_nparts;
+                        for (int k = 0; k < p.a_nparts; ++k) { const float d = q[2 * k] - mean; m2 += 64.0f * (d * d); }
+                    }
                     rstd = 1.0f / sqrtf(m2 / (64.0f * (float)p.a_nparts) + p.a_eps);
                 } else {
                     mean = p.a_mean[row];
