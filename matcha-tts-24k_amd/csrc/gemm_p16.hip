@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                 const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
                 for (int k = j; k < nrw * nw; k += 16) {
                     const int rw = k / nw, w = w_lo + (k - rw * nw);
-                    const float* q = p.gnr_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4;
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(p.gnr_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4);
                     const float nb = q[0];
                     if (nb <= 0.f) continue;
                     const float delta = q[1] - mean, nt = n + nb;

@@ -245,7 +245,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
             for (int k = j; k < nrw * nw; k += L) {
                 const int rw = k / nw, w = w_lo + (k - rw * nw);
                 const int slice = g - (w * 64) / cpg;
-                const float* q = p.tile_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + slice) * 4;
+                const f32x4 q = *reinterpret_cast<const f32x4*>(p.tile_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + slice) * 4);
                 const float nb = q[0];
                 if (nb <= 0.f) continue;
                 const float delta = q[1] - mean;
