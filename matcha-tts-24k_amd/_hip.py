@@ -45,13 +45,31 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     #   lanes 48-63 of a wave on gfx950 (a missing wait state after the packed op; reproduced with tools/_dbg_stats.py,
     #   gone with scalar fp32 ops).  Packed fp32 VALU is also slower beside MFMAs (cdna_hip_programming.md).
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           *os.environ.get("MTTS_HIPCC_EXTRA", "").split(), *[str(s) for s in srcs], "-o", str(LIB)]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+             *os.environ.get("MTTS_HIPCC_EXTRA", "").split()]
+    # one translation unit per process (the GEMM files instantiate dozens of kernels each), objects in build/, then one link
+    objdir = HERE / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{res.stdout}\n{res.stderr}")
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
     return LIB
 
 
