@@ -85,39 +85,44 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
         constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows (p.res), 2 a P16 image (p.res16), 3 Block1D tail (gnr_*)
         constexpr bool RES = RESK == 1 || RESK == 3;          // both prefetch fp32 rows
-        // chunks of U passes (4 U rows of the tile): all of a chunk's residual / mask loads are in flight together
+        // chunks of U passes (4 U rows of the tile): all of a chunk's residual / mask loads are in flight together, and the
+        // next chunk's are requested before this one is computed and stored (two register sets; the accumulators are dead)
         constexpr int U = 4;
-        for (int c0 = 0; c0 < NIT; c0 += U) {
+        struct ChunkLoads {
             int orow[U];
             bool ok[U];
-            float om[U], om16[U], gmk[RESK == 3 ? U : 1];
-            f32x4 rres[RES ? U : 1];
-            f16x4 r16h[RESK == 2 ? U : 1], r16l[RESK == 2 ? U : 1];
+            float om[U], om16[U], gmk[U];
+            f32x4 rres[U];
+            f16x4 r16h[U], r16l[U];
+        };
+        auto load_chunk = [&](int c0, ChunkLoads& L) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int m = m0 + wm * (BM / 2) + (c0 + u) * 4 + (lane >> 4);
-                ok[u] = m < M && col_ok;
+                L.ok[u] = m < M && col_ok;
                 const int mc = m < M ? m : M - 1;
                 int r = mc;
                 if (!plain_rows) {
                     const int b = mc / p.T_out;
                     r = b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
                 }
-                orow[u] = r;
-                om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
-                om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
-                if constexpr (RESK == 1) rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
+                L.orow[u] = r;
+                L.om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
+                L.om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
+                if constexpr (RESK == 1) L.rres[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + (col_ok ? nc : 0));
                 if constexpr (RESK == 3) {
-                    rres[u] = *reinterpret_cast<const f32x4*>(p.gnr_y + (size_t)r * p.N + (col_ok ? nc : 0));
-                    gmk[u] = p.gnr_mask[r];
+                    L.rres[u] = *reinterpret_cast<const f32x4*>(p.gnr_y + (size_t)r * p.N + (col_ok ? nc : 0));
+                    L.gmk[u] = p.gnr_mask[r];
                 }
                 if constexpr (RESK == 2) {
                     const int ncl = col_ok ? nc : 0;
                     const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
-                    r16h[u] = *reinterpret_cast<const f16x4*>(q);
-                    r16l[u] = *reinterpret_cast<const f16x4*>(q + 32);
+                    L.r16h[u] = *reinterpret_cast<const f16x4*>(q);
+                    L.r16l[u] = *reinterpret_cast<const f16x4*>(q + 32);
                 }
             }
+        };
+        auto process_chunk = [&](int c0, const ChunkLoads& L) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int rl = (c0 + u) * 4 + (lane >> 4);
@@ -140,30 +145,30 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], p.act, s0[e], s1[e]);
                 }
-                o *= om[u];
+                o *= L.om[u];
                 if (p.out_scale != 1.0f) o *= p.out_scale;
-                if constexpr (RESK == 1) o += rres[u];
+                if constexpr (RESK == 1) o += L.rres[u];
                 if constexpr (RESK == 3) {           // Mish(GroupNorm(y)) * mask, same operation order as gn_apply_kernel
-                    f32x4 v = ((rres[u] - gnr_mu) * gnr_rs) * gnr_gm + gnr_bt;
+                    f32x4 v = ((L.rres[u] - gnr_mu) * gnr_rs) * gnr_gm + gnr_bt;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = mish_f(v[e]) * gmk[u];
+                    for (int e = 0; e < 4; ++e) v[e] = mish_f(v[e]) * L.gmk[u];
                     o += v;
                 }
                 if constexpr (RESK == 2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += (float)r16h[u][e] + (float)r16l[u][e] * (1.0f / F16_RES_SCALE);
+                    for (int e = 0; e < 4; ++e) o[e] += (float)L.r16h[u][e] + (float)L.r16l[u][e] * (1.0f / F16_RES_SCALE);
                 }
-                if (ok[u]) {
-                    if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)orow[u] * p.ldc + nc) = o;
+                if (L.ok[u]) {
+                    if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)L.orow[u] * p.ldc + nc) = o;
                     if (p.out16) {                           // P16 copy: 8 lanes write one whole 128-B line
                         f16x4 h, l;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = o[e] * om16[u];
+                            const float v = o[e] * L.om16[u];
                             h[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
                             l[e] = (_Float16)fminf(fmaxf((v - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
                         }
-                        _Float16* o16 = p.out16 + (size_t)orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
+                        _Float16* o16 = p.out16 + (size_t)L.orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
                         *reinterpret_cast<f16x4*>(o16) = h;
                         *reinterpret_cast<f16x4*>(o16 + 32) = l;
                     }
@@ -172,13 +177,22 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                     const float mu = allreduce16((o[0] + o[1]) + (o[2] + o[3])) * (1.0f / 64.0f);
                     const f32x4 d = o - mu;
                     const float m2 = allreduce16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
-                    if ((lane & 15) == 0 && ok[u]) {
-                        float* so = p.stats_out + ((size_t)orow[u] * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                    if ((lane & 15) == 0 && L.ok[u]) {
+                        float* so = p.stats_out + ((size_t)L.orow[u] * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
                         so[0] = mu;
                         so[1] = m2;
                     }
                 }
             }
+        };
+        ChunkLoads LA, LB;
+        load_chunk(0, LA);
+#pragma unroll
+        for (int c0 = 0; c0 < NIT; c0 += 2 * U) {
+            if (c0 + U < NIT) load_chunk(c0 + U, LB);
+            process_chunk(c0, LA);
+            if (c0 + 2 * U < NIT) load_chunk(c0 + 2 * U, LA);
+            if (c0 + U < NIT) process_chunk(c0 + U, LB);
         }
     };
     const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
