@@ -178,6 +178,12 @@ int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, in
 /* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
 int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);
 
+/* Channel LayerNorm of the text encoder -- reference text_encoder.py:19-27 -- over x [B*T, C] rows, optionally followed by
+ * SiLU (act = 2: ConvSiluNorm, text_encoder.py:58-60), the DurationPredictor's speaker FiLM `* gamma_b + beta_b`
+ * (d_film [B, 2C] = gamma | beta, text_encoder.py:102-109) and the row mask (d_mask [B*T]).  Null pointers skip a stage. */
+int mtts_channel_layernorm(const float* d_x, int B, int T, int C, const float* d_gamma, const float* d_beta, float eps, int act,
+                           const float* d_film, const float* d_mask, float* d_y, void* stream);
+
 /* Block1D tail -- reference decoder.py:38-45: Mish(GroupNorm_G(y)) * mask over y [B,T,C] (channels last);
  * statistics over (C/G channels x all T frames).  d_scratch: mtts_groupnorm_scratch_bytes. */
 int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G);

@@ -112,6 +112,7 @@ def load() -> C.CDLL:
                                 i32, vp, f32, vp, i32, vp, i32, vp]),
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
+        "mtts_channel_layernorm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
         "mtts_groupnorm_mish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_vocos_create": (vp, [i32, i32, i32, i32, i32, i32]),
@@ -412,6 +413,15 @@ def row_stats(x, eps=1e-5):
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
     check(lib.mtts_row_stats(ptr(x), M, Cc, Cc, eps, ptr(mean), ptr(rstd), stream_ptr()))
     return mean, rstd
+
+
+def channel_layernorm(x, gamma, beta, B, T, *, act=0, film=None, mask=None, eps=1e-5):
+    """x [B*T, C] rows; film [B, 2C] = gamma | beta of the DurationPredictor's speaker FiLM; mask [B*T]."""
+    lib = load()
+    y = torch.empty_like(x)
+    check(lib.mtts_channel_layernorm(ptr(x), B, T, x.shape[1], ptr(gamma), ptr(beta), float(eps), act, ptr(film), ptr(mask), ptr(y),
+                                     stream_ptr()))
+    return y
 
 
 def groupnorm_mish(y, gamma, beta, mask, B, T, G=8, eps=1e-5):

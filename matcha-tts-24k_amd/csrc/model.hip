@@ -1308,6 +1308,17 @@ int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_m
     return 0;
 }
 
+int mtts_channel_layernorm(const float* d_x, int B, int T, int C, const float* d_gamma, const float* d_beta, float eps, int act,
+                           const float* d_film, const float* d_mask, float* d_y, void* stream) {
+    if (B <= 0 || T <= 0) { set_error("mtts_channel_layernorm: empty batch"); return -1; }
+    if (act != ACT_NONE && act != ACT_SILU) { set_error("mtts_channel_layernorm: act must be 0 (none) or 2 (SiLU)"); return -1; }
+    LayerNormArgs a;
+    a.x = d_x; a.ldx = C; a.y = d_y; a.ldy = C; a.M = B * T; a.C = C; a.T = T; a.gamma = d_gamma; a.beta = d_beta; a.eps = eps;
+    a.act = act; a.film = d_film; a.mask = d_mask;
+    HIP_OK(launch_layernorm(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int64_t mtts_groupnorm_scratch_bytes(int B, int T, int G) { return (int64_t)B * gn_chunks_max(T) * G * 2 * (int64_t)sizeof(float); }
 
 int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_beta, const float* d_mask, int B, int T, int C, int G,

@@ -16,6 +16,13 @@ only small id arrays and expected outputs are stored):
   prod_synth.npz     prod v20 shapes, Tx=128: logw, mu_y, 1-NFE decoder output, mel for euler/2, euler/10, midpoint/4
   prod_batch.npz     prod shapes, B=3 ragged lengths, euler/2 (reference components composed as synthesise does)
   randn42.npz        first values of the CPU seed-42 normal stream (detects an RNG mismatch on another box)
+  dp_tiny.npz        duration_recipe=False (non-zero DurationPredictor projection, reference text_encoder.py:64-112):
+                     B=3 ragged encoder outputs, the reference's own durations / lengths (inference.py:127-146 replayed)
+                     and the euler/2 mel; per-utterance MatchaTTSInfer.synthesise durations + mel
+  dp_prod.npz        the same at prod v20 shapes: B=2 ragged (Tx=128, 96) encoder + durations + lengths, and the
+                     single-utterance synthesise (Tx=128) durations + euler/2 mel
+                     (``margin`` = distance of exp(logw)-2 from the nearest rounding boundary: the seeds are chosen so that
+                     an fp32-rounding-level difference in logw cannot flip a duration)
 """
 import importlib
 import os
@@ -194,13 +201,62 @@ def main():
     np.savez(HERE / "prod_batch.npz", x=x.numpy(), x_lengths=x_len.numpy(), speakers=spk.numpy(),
              mel=rb["mel"].numpy(), y_lengths=rb["y_lengths"].numpy())
 
+    # ------------------------------------------------------------------ duration predictor live (duration_recipe=False)
+    def dp_fixture(tag, hp, lengths, seed_w, seed_x, sc, ls, steps=2):
+        sd = synthetic.make_state_dict(hp, seed=seed_w, duration_recipe=False)
+        assert float(sd["encoder.proj_w.proj.weight"].abs().max()) > 0
+        model = build_ref_model(ref_inf, hp, sd)
+        model.decoder.solver = "euler"
+        B, Tx = len(lengths), max(lengths)
+        x, x_len, spk = synthetic.make_inputs(hp, B, Tx, seed=seed_x, lengths=lengths)
+        e_enc, e_dur = model.speaker_embeddings_enc(spk), model.speaker_embeddings_dur(spk)
+        mu_x, logw, x_mask = model.encoder(x, x_len, e_enc, e_dur)
+        o_mu, o_logw, _ = O.text_encoder_forward(sd, hp, x, x_len, sd["speaker_embeddings_enc.weight"][spk],
+                                                 sd["speaker_embeddings_dur.weight"][spk])
+        report[f"{tag}.encoder.mu_x"] = maxabs(mu_x, o_mu)
+        report[f"{tag}.encoder.logw"] = maxabs(logw, o_logw)
+        valid = x_mask.squeeze(1) > 0
+        report[f"{tag}.logw.std(valid)"] = float(logw.squeeze(1)[valid].std())
+        # inference.py:127-146 replayed on the batch with the reference's own helpers
+        raw = ((torch.exp(logw) - 2) * x_mask).squeeze(1) * sc * ls
+        margin = float(((raw - raw.floor() - 0.5).abs())[valid].min())       # distance from a round-half boundary
+        margin = min(margin, float((raw - 0.5).abs()[valid].min()))
+        rb = ref_batched(model, x, x_len, spk, steps, sc, ls)
+        dur = (raw.round().clamp(min=1) * x_mask.squeeze(1))
+        od = O.durations_from_logw(o_logw, x_mask, sc, ls)
+        report[f"{tag}.durations.equal"] = float(torch.equal(dur, od))
+        report[f"{tag}.durations.margin"] = margin
+        report[f"{tag}.durations.minmax"] = f"{int(dur[valid].min())}..{int(dur[valid].max())}"
+        oo = O.synthesise(sd, hp, x, x_len, steps, speaker=spk, scale_correction=sc, length_scale=ls, solver="euler")
+        report[f"{tag}.batch.mel"] = maxabs(rb["mel"], oo["mel"])
+        rec = dict(x=x.numpy(), x_lengths=x_len.numpy(), speakers=spk.numpy(), mu_x=mu_x.numpy(), logw=logw.numpy(),
+                   durations=dur.numpy(), y_lengths=rb["y_lengths"].numpy(), mu_y=rb["mu_y"].numpy(), mel=rb["mel"].numpy(),
+                   margin=np.array(margin), sc=np.array(sc), ls=np.array(ls), seed_w=np.array(seed_w), seed_x=np.array(seed_x),
+                   steps=np.array(steps))
+        # the reference's own batch-1 synthesise on utterance 0 (its phoneme_durations come out of inference.py itself)
+        n0 = int(x_len[0])
+        out = model.synthesise(x[:1, :n0], x_len[:1], n_timesteps=steps, speaker=int(spk[0]), scale_correction=sc,
+                               length_scale=ls, debug=True)
+        o1 = O.synthesise(sd, hp, x[:1, :n0], x_len[:1], steps, speaker=int(spk[0]), scale_correction=sc, length_scale=ls,
+                          solver="euler")
+        report[f"{tag}.synth.b0.mel"] = maxabs(out["mel"], o1["mel"])
+        report[f"{tag}.synth.b0.dur_equal"] = float(torch.equal(out["phoneme_durations"], o1["durations"]))
+        rec["solo_dur"] = out["phoneme_durations"].numpy()
+        rec["solo_mel"] = out["mel"].numpy()
+        np.savez(HERE / f"{tag}.npz", **rec)
+        return margin
+
+    m1 = dp_fixture("dp_tiny", hparams.tiny(n_spks=2), [12, 9, 4], seed_w=7, seed_x=1234, sc=1.03, ls=0.9)
+    m2 = dp_fixture("dp_prod", hparams.prod_v20(n_spks=3), [128, 96], seed_w=7, seed_x=1234, sc=1.0, ls=1.0)
+    assert min(m1, m2) > 2e-3, ("pick other seeds: a duration sits on a rounding boundary", m1, m2)
+
     np.savez(HERE / "randn42.npz", head=synthetic.cpu_noise((1, 100, 640)).flatten()[:16].numpy(),
              tail=synthetic.cpu_noise((1, 100, 640)).flatten()[-16:].numpy())
 
     print("oracle vs reference, max-abs:")
     for k, v in report.items():
         print(f"  {k:32s} {v:.3e}" if isinstance(v, float) else f"  {k:32s} {v}")
-    worst = max(v for v in report.values() if isinstance(v, float))
+    worst = max(v for k, v in report.items() if isinstance(v, float) and not k.endswith(("margin", "equal", "std(valid)", "dur_equal")))
     print("worst:", worst)
     (HERE / "REPORT.txt").write_text("\n".join(f"{k} {v}" for k, v in report.items()) + "\n")
 

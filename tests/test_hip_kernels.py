@@ -306,3 +306,28 @@ def test_groupnorm_mish(hip, B, T, C):
     ref = (F.mish(F.group_norm(x, 8, g.double(), b.double(), eps=1e-5)) * mask.view(B, 1, T).double()).transpose(1, 2).reshape(-1, C)
     out = hip.groupnorm_mish(y.cuda(), g.cuda(), b.cuda(), mask.cuda(), B, T)
     close(out, ref, 3e-6)
+
+
+@pytest.mark.parametrize("B,T,C,act,film,mask", [(3, 37, 96, 0, True, True), (2, 128, 256, 0, True, False), (2, 50, 192, 2, False, True),
+                                                   (1, 1, 96, 0, True, True)])
+def test_channel_layernorm_film(hip, B, T, C, act, film, mask):
+    """layernorm_kernel: channel LayerNorm (biased variance, reference text_encoder.py:19-27) + SiLU (ConvSiluNorm) or the
+    DurationPredictor's per-utterance FiLM `x * gamma_b + beta_b` (text_encoder.py:102-109) + row mask, against fp64."""
+    x = rnd(B * T, C, seed=1, scale=3.0) + 0.7
+    g, b = 1.0 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    fm = (rnd(B, 2 * C, seed=4) + 0.5) if film else None
+    mk = (rnd(B * T, seed=5) > -0.3).float() if mask else None
+    xd = x.double()
+    mean = xd.mean(1, keepdim=True)
+    var = ((xd - mean) ** 2).mean(1, keepdim=True)
+    ref = (xd - mean) * torch.rsqrt(var + 1e-5) * g.double() + b.double()
+    if act == 2:
+        ref = F.silu(ref)
+    if film:
+        fb = fm.double().repeat_interleave(T, dim=0)
+        ref = ref * fb[:, :C] + fb[:, C:]
+    if mask:
+        ref = ref * mk.double()[:, None]
+    out = hip.channel_layernorm(x.cuda(), g.cuda(), b.cuda(), B, T, act=act, film=None if fm is None else fm.cuda(),
+                                mask=None if mk is None else mk.cuda())
+    close(out, ref, 3e-6)

@@ -357,6 +357,42 @@ def test_config2_batch32_properties(prod, synthetic, dev):
         assert maxabs(out[:1], _t(g["mel_euler10"])) < MEL_TOL
 
 
+# ------------------------------------------------------------------------------------------------ duration predictor live
+@pytest.mark.parametrize("tag,which", [("dp_tiny", "tiny"), ("dp_prod", "prod")])
+def test_duration_predictor_live_vs_golden(tag, which, hparams, synthetic, dev):
+    """duration_recipe=False fixtures recorded from the reference (tests/golden/make_golden.py `dp_fixture`): the
+    DurationPredictor's conv -> ReLU -> LN -> FiLM stack (reference text_encoder.py:64-112) decides logw, so durations vary
+    per token (1..83 frames at prod shapes).  logw to 2e-5, the integer durations / lengths bit-equal (the fixture's seeds keep
+    every exp(logw)-2 at least 5e-4 (relative) away from a rounding boundary), mu_y and the mel inside the path's tolerance."""
+    g = np.load(GOLDEN / f"{tag}.npz")
+    hp = hparams.tiny(n_spks=2) if which == "tiny" else hparams.prod_v20(n_spks=3)
+    sd = synthetic.make_state_dict(hp, seed=int(g["seed_w"]), duration_recipe=False)
+    model = make_model(hp, sd, dev)
+    lengths = [int(v) for v in g["x_lengths"]]
+    x, x_len, spk = synthetic.make_inputs(hp, len(lengths), max(lengths), seed=int(g["seed_x"]), lengths=lengths)
+    assert np.array_equal(x.numpy(), g["x"])
+    sc, ls, steps = float(g["sc"]), float(g["ls"]), int(g["steps"])
+    logw_g = _t(g["logw"])
+    assert float(logw_g[:, 0, : min(lengths)].std()) > 0.3          # not the constant-duration recipe
+    model.decoder.solver = "euler"
+    z = lambda t_pad: synthetic.cpu_noise((len(lengths), hp.n_feats, t_pad)).to(dev)
+    out = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev), scale_correction=sc, length_scale=ls,
+                           debug=True, z=z)
+    assert maxabs(out["logw"], logw_g) < 2e-5
+    assert maxabs(out["mu_x"], _t(g["mu_x"])) < 2e-5
+    assert torch.equal(out["phoneme_durations"].cpu(), _t(g["durations"]))
+    assert torch.equal(out["mel_lengths"].cpu(), _t(g["y_lengths"]))
+    assert out["mu_y"].shape == g["mu_y"].shape and maxabs(out["mu_y"], _t(g["mu_y"])) < 2e-5
+    assert out["mel"].shape == g["mel"].shape
+    assert maxabs(out["mel"], _t(g["mel"])) < MEL_TOL
+    # the reference's own batch-1 synthesise of utterance 0
+    n0 = lengths[0]
+    solo = model.synthesise(x[:1, :n0].to(dev), x_len[:1].to(dev), steps, speaker=int(spk[0]), scale_correction=sc,
+                            length_scale=ls, debug=True, z=lambda t_pad: synthetic.cpu_noise((1, hp.n_feats, t_pad)).to(dev))
+    assert torch.equal(solo["phoneme_durations"].cpu(), _t(g["solo_dur"]))
+    assert maxabs(solo["mel"], _t(g["solo_mel"])) < MEL_TOL
+
+
 # ------------------------------------------------------------------------------------------------ API behaviour
 def test_api_surface(tiny, synthetic, dev):
     hp, sd, model = tiny

@@ -100,3 +100,34 @@ def test_prod_ragged_batch(hparams, synthetic, oracle):
         out = oracle.synthesise(sd, hp, x, x_len, 2, speaker=spk, solver="euler")
     assert torch.equal(out["mel_lengths"], _t(g["y_lengths"]))
     assert (out["mel"] - _t(g["mel"])).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("tag,which", [("dp_tiny", "tiny"), ("dp_prod", "prod")])
+def test_duration_predictor_live(tag, which, hparams, synthetic, oracle):
+    """duration_recipe=False: the DurationPredictor's conv/ReLU/LN/FiLM stack decides logw (reference text_encoder.py:64-112),
+    hence the durations, T_pad and everything downstream (inference.py:127-146).  Fixtures recorded from the reference."""
+    g = np.load(GOLDEN / f"{tag}.npz")
+    hp = hparams.tiny(n_spks=2) if which == "tiny" else hparams.prod_v20(n_spks=3)
+    sd = synthetic.make_state_dict(hp, seed=int(g["seed_w"]), duration_recipe=False)
+    lengths = [int(v) for v in g["x_lengths"]]
+    x, x_len, spk = synthetic.make_inputs(hp, len(lengths), max(lengths), seed=int(g["seed_x"]), lengths=lengths)
+    assert np.array_equal(x.numpy(), g["x"]) and np.array_equal(spk.numpy(), g["speakers"])
+    sc, ls, steps = float(g["sc"]), float(g["ls"]), int(g["steps"])
+    logw_g = _t(g["logw"])
+    valid = oracle.sequence_mask(x_len, max(lengths))
+    assert float(logw_g[:, 0][valid].std()) > 0.3            # the fixture is NOT the constant-duration recipe
+    with torch.inference_mode():
+        out = oracle.synthesise(sd, hp, x, x_len, steps, speaker=spk, scale_correction=sc, length_scale=ls, solver="euler")
+    assert (out["logw"] - logw_g).abs().max() < TOL
+    assert (out["mu_x"] - _t(g["mu_x"])).abs().max() < TOL
+    assert torch.equal(out["durations"], _t(g["durations"]))
+    assert torch.equal(out["mel_lengths"], _t(g["y_lengths"]))
+    assert (out["mu_y"] - _t(g["mu_y"])).abs().max() < TOL
+    assert (out["mel"] - _t(g["mel"])).abs().max() < 2e-4
+    if which == "tiny":     # the reference's own batch-1 synthesise (its phoneme_durations)
+        n0 = lengths[0]
+        with torch.inference_mode():
+            solo = oracle.synthesise(sd, hp, x[:1, :n0], x_len[:1], steps, speaker=int(spk[0]), scale_correction=sc,
+                                     length_scale=ls, solver="euler")
+        assert torch.equal(solo["durations"], _t(g["solo_dur"]))
+        assert (solo["mel"] - _t(g["solo_mel"])).abs().max() < 1e-4
