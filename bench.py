@@ -7,8 +7,11 @@ Workload at N=1 = BASELINE.json configs[1]: batch 32 random phoneme sequences of
 prod v20 architecture with random-init weights (no checkpoints exist offline), 5 fine frames per token, i.e.
 T_pad = 640 decoder frames and 320 valid mel frames per utterance, strict reference padding.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): utterances shard data-parallel, every rank synthesises its
-own 32 utterances (weak scaling) and the finished mels are all-gathered over RCCL inside the timed step.
+N>1: one rank per GPU; utterances shard data-parallel, every rank synthesises its own 32 utterances (weak scaling) and the
+finished mels are all-gathered over RCCL inside the timed step.  Either launch it under torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or plainly as `python bench.py --gpus N`: the parent then starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process before it has
+touched the GPU (never an exec after device init), relays the child's output and exits with its return code.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-events]
 prints ONE JSON line on rank 0.
@@ -25,6 +28,33 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _self_launch_if_needed():
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks as a child torch.distributed.run job.
+    Runs before torch is imported in this process, so the parent never initialises a device."""
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
 
 import torch
 import torch.distributed as dist
@@ -65,20 +95,23 @@ def algorithmic_flops(hp, batch, t_pad, tx, nfe):
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-    separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot collect PMC
-    counters itself, so the committed summary of the latest run under profiles/ is reported (null if absent)."""
+    """HBM bytes per GEMM launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate runs,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect PMC counters itself: the value
+    is READ from the committed summary profiles/pmc_traffic_latest.json (written by tools/profile_gpu.sh on an earlier box) and
+    is labelled as such in `traffic_source`; null if absent."""
     f = ROOT / "profiles" / "pmc_traffic_latest.json"
     if not f.exists():
-        return None
+        return None, None
     try:
-        return json.loads(f.read_text())["gemm_hbm_mb_per_launch"]
+        d = json.loads(f.read_text())
+        return d["gemm_hbm_mb_per_launch"], f"profiles/pmc_traffic_latest.json ({d.get('label', 'committed rocprofv3 --pmc summary')}; NOT measured in this run)"
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(hp, sd, synthetic, budget_s=12.0):
-    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(hp, sd, synthetic):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores at B=32 (the bench workload) and B=1, as
+    BASELINE.md section 4 asks: warm-up, then the median of 3 (B=32, ~10 s each) / 5 (B=1) runs."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import matcha_oracle as O
     try:
@@ -87,22 +120,37 @@ def cpu_baseline(hp, sd, synthetic, budget_s=12.0):
         avail = os.cpu_count() or 1
     threads = min(avail, 16)            # a 1-GPU box's CPU share is 16 cores; oversubscribing torch's pool is slower
     torch.set_num_threads(threads)
-    b = 2
-    x, x_len, _ = synthetic.make_inputs(hp, b, N_TOKENS, seed=1234)
-    frames, reps = 0, 0
-    with torch.inference_mode():
-        O.synthesise(sd, hp, x[:1], x_len[:1], 1, speaker=0, solver=SOLVER)   # warm the thread pool
-        t0 = time.perf_counter()
-        while True:
-            out = O.synthesise(sd, hp, x, x_len, N_STEPS_ODE, speaker=0, solver=SOLVER)
-            frames += int(out["mel_lengths"].sum())
-            reps += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s and reps >= 2:
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
                 break
-    return {"value": round(frames / el, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x synthesise(B={b}, Tx={N_TOKENS}, {SOLVER}/{N_STEPS_ODE}) = {frames} valid frames in {el:.1f}s, "
-                      f"oracle/matcha_oracle.py, torch CPU fp32, {threads} threads"}
+    except Exception:
+        pass
+
+    def timed(b, reps):
+        x, x_len, _ = synthetic.make_inputs(hp, b, N_TOKENS, seed=1234)
+        ts, frames = [], 0
+        with torch.inference_mode():
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                out = O.synthesise(sd, hp, x, x_len, N_STEPS_ODE, speaker=0, solver=SOLVER)
+                ts.append(time.perf_counter() - t0)
+                frames = int(out["mel_lengths"].sum())
+        ts.sort()
+        return frames, ts[len(ts) // 2], ts
+
+    with torch.inference_mode():        # warm the thread pool and the allocator
+        x, x_len, _ = synthetic.make_inputs(hp, 2, N_TOKENS, seed=1234)
+        O.synthesise(sd, hp, x, x_len, 1, speaker=0, solver=SOLVER)
+    f1, m1, t1 = timed(1, 5)
+    f32_, m32, t32 = timed(BATCH, 3)
+    return {"value": round(f32_ / m32, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "value_b1": round(f1 / m1, 1), "cpu_model": cpu_model,
+            "sample": f"oracle/matcha_oracle.py synthesise(Tx={N_TOKENS}, {SOLVER}/{N_STEPS_ODE}), torch CPU fp32, {threads} threads: "
+                      f"B={BATCH} median of 3 runs ({', '.join(f'{t:.2f}' for t in t32)} s for {f32_} valid frames) = value; "
+                      f"B=1 median of 5 runs ({', '.join(f'{t:.2f}' for t in t1)} s for {f1} frames) = value_b1"}
 
 
 def main():
@@ -125,15 +173,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and world == 1:      # unreachable from the command line (_self_launch_if_needed), kept for importers
+        raise SystemExit("--gpus N>1 needs one rank per GPU: run `python bench.py --gpus N` or launch under torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    # MTTS_DIST_BACKEND=gloo: rehearsal of the N-rank job on fewer cards (ranks share devices, collectives staged through host
+    # memory by dp.py) -- labelled in the output, never the scaling measurement, which runs one rank per GPU over RCCL
+    backend = os.environ.get("MTTS_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and n_dev < world:
+        raise SystemExit(f"--gpus {world} needs {world} devices for RCCL (found {n_dev}); set MTTS_DIST_BACKEND=gloo to rehearse")
+    local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     hparams = importlib.import_module(PKG + ".hparams")
     synthetic = importlib.import_module(PKG + ".synthetic")
@@ -178,7 +235,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     valid_per_utt = mel.shape[-1]
@@ -209,7 +266,7 @@ def main():
         roofline = {
             "bound": "mfma", "kernel": "gemm_p16_kernel + gemm_f32_kernel (GEMM / implicit conv1d, all instantiations)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
+            "frac": round(achieved / peak, 4), "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
             "peak_basis": f"{hw_peak:.0f} TFLOP/s dense ({instr}) / {products}",
             "mfma_executed_tflops": round(achieved * products, 1),
             "algorithmic_mb_per_launch": round(by_g / max(n_g, 1) / 1e6, 2),
@@ -237,7 +294,7 @@ def main():
                                    "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
                                    "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "
                                    "(reference 2x padding), noise from the device seed-42 generator",
-                       "per_gpu_batch": BATCH, "global_batch": BATCH * world, "n_tokens": N_TOKENS, "parallelism": f"dp{world}",
+                       "per_gpu_batch": BATCH, "global_batch": BATCH * world, "n_tokens": N_TOKENS, "parallelism": f"dp{world}" + ("" if backend == "nccl" or world == 1 else f" REHEARSAL over {backend} on {n_dev} device(s)"),
                        "n_feats": hp.n_feats, "note": "the reference fork uses 100 mel bins (Vocos-24k), not 80"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

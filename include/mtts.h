@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MTTS_ABI_VERSION 1
+#define MTTS_ABI_VERSION 2
 
 typedef struct mtts_ctx mtts_ctx;
 
@@ -127,6 +127,26 @@ int mtts_decoder_forward(mtts_ctx* ctx, const float* d_x, const float* d_mask, c
 int mtts_cfm_solve(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const float* d_mask, int add_mu,
                    const float* h_t_span, int n_steps, int solver, int B, int T, float* d_out, int T_out,
                    float out_scale, float out_shift, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* The same solve on FOLDED padding -- what MatchaTTSInfer.synthesise runs (reference matcha/inference.py:146-170 pads the
+ * decoder to T = roundup_even(longest fine length), i.e. twice the valid mel length, and GroupNorm / attention see those
+ * frames: decoder.py:32-45, transformer.py:249-261).  With prefix masks (frame t of utterance b valid iff t < d_y_lengths[b])
+ * every padded frame of a U-Net level is the same row: convolutions read `x * mask` (decoder.py:43,62), so beyond the first
+ * padded frame a conv output is its bias, a ResNet output is the residual conv's bias, and transformer blocks act row-wise with
+ * keys that carry no position.  The estimator therefore holds, per utterance and level l, the ceil(y_len / 2^l) valid rows plus
+ * ONE row standing for the n_pad padded ones: attention gives that key the bias ln(n_pad) (n_pad reference keys of bias +0),
+ * GroupNorm merges the remaining n_pad - 1 bias rows in closed form.  Same results as mtts_cfm_solve on the full [B, n_feats, T]
+ * problem up to summation order; T_fold / T of the arithmetic.
+ *   d_x0, d_mu [B, n_feats, T] as for mtts_cfm_solve (only frames < T_fold are read; frames of the state at or beyond an
+ *   utterance's own length pass through unchanged, as in the reference); d_y_lengths device int64 [B], all <= y_max < T.
+ *   T_fold: rows held per utterance, a multiple of 2^(levels-1) with mtts_fold_rows(ctx, y_max, 1) <= T_fold <= T;
+ *   mtts_fold_rows(ctx, y_max, align) = roundup(ceil(y_max / 2^(levels-1)) + 1, align) * 2^(levels-1) (align 32 keeps whole
+ *   wave tiles per utterance for the fused GroupNorm statistics).  Workspace: mtts_decoder_workspace_bytes(ctx, B, T_fold).
+ *   mtts_set_frame_limits composes: utterance b's reference length is then d_t_len[b] instead of T. */
+int mtts_fold_rows(mtts_ctx* ctx, int y_max, int align);
+int mtts_cfm_solve_folded(mtts_ctx* ctx, const float* d_x0, const float* d_mu, const int64_t* d_y_lengths, int y_max, int add_mu,
+                          const float* h_t_span, int n_steps, int solver, int B, int T, int T_fold, float* d_out, int T_out,
+                          float out_scale, float out_shift, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- single kernels (parity tests, building blocks) */
 

@@ -32,12 +32,31 @@ class MttsConfig(C.Structure):
             "dec_head_dim", "dec_heads", "dec_n_blocks", "dec_mid_blocks")]
 
 
+def _deps(src: Path, seen=None):
+    """The source and the local headers it includes, transitively (quoted #include lines)."""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not src.exists():
+        return seen
+    seen.add(src)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', src.read_text(), flags=re.M):
+        _deps((src.parent / inc).resolve(), seen)
+    return seen
+
+
+BUILD_MODE = "not built in this process"     # what the last build() call did (printed by __graft_entry__.build)
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 into libmtts_hip.so next to this file (cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 into libmtts_hip.so next to this file (cross-compiles without a GPU).
+    Incremental: a translation unit is recompiled when it or a header it includes is newer than its object; the link runs
+    when any object is newer than the library.  ``BUILD_MODE`` records what happened (compiled / reused)."""
+    global BUILD_MODE
     srcs = [CSRC / s for s in SOURCES]
     if LIB.exists() and not force:
         newest = max(p.stat().st_mtime for p in srcs + HEADERS)
         if LIB.stat().st_mtime >= newest:
+            BUILD_MODE = f"reused {LIB.name} (newer than every source and header)"
             return LIB
     # -ffp-contract=off: keep the reference's rounding points (no silent FMA fusion in the element-wise math).
     # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent fp32 ops into v_pk_mul_f32 / v_pk_add_f32; in the
@@ -51,8 +70,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = HERE / "build"
     objdir.mkdir(exist_ok=True)
 
+    compiled = []
+
     def compile_one(src: Path) -> Path:
         obj = objdir / (src.stem + ".o")
+        if obj.exists() and not force and obj.stat().st_mtime >= max(p.stat().st_mtime for p in _deps(src.resolve())):
+            return obj
+        compiled.append(src.name)
         cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
@@ -70,6 +94,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
+    BUILD_MODE = f"compiled {', '.join(sorted(compiled)) or 'nothing'} with hipcc --offload-arch=gfx950 and linked {LIB.name}"
     return LIB
 
 
@@ -103,6 +128,8 @@ def load() -> C.CDLL:
         "mtts_decoder_workspace_bytes": (i64, [vp, i32, i32]),
         "mtts_decoder_forward": (i32, [vp, vp, vp, vp, f32, i32, i32, vp, vp, i64, vp]),
         "mtts_cfm_solve": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
+        "mtts_fold_rows": (i32, [vp, i32, i32]),
+        "mtts_cfm_solve_folded": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, f32, f32, vp, i64, vp]),
         "mtts_gemm_packed_bytes": (i64, [i32, i32, i32]),
         "mtts_attention_p16": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp]),
         "mtts_gemm_p16_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
@@ -131,7 +158,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mtts_abi_version() != 1:
+    if lib.mtts_abi_version() != 2:
         raise RuntimeError("libmtts_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -242,16 +269,26 @@ class HipModel:
         self._ws.clear()
 
     def _workspace(self, kind: str, a: int, b: int) -> torch.Tensor:
-        key = (kind, a, b, stream_ptr())      # one workspace per stream: concurrent calls on different streams must not share scratch
+        """One GROW-ONLY scratch buffer per (kind, stream): a serving process sees a new (B, T_pad) with almost every request,
+        so buffers keyed by shape would pin HBM without bound.  The C side takes (pointer, byte count) and bump-allocates what
+        the call needs from the front.  Concurrent calls on different streams must not share scratch, hence the stream key;
+        a buffer being replaced stays alive until the work queued on its stream has drained (torch's caching allocator frees
+        a block for re-use in stream order)."""
+        fn = self.lib.mtts_decoder_workspace_bytes if kind == "dec" else self.lib.mtts_encoder_workspace_bytes
+        n = fn(self.ctx, a, b)
+        if n < 0:
+            check(-1)
+        key = (kind, stream_ptr())
         ws = self._ws.get(key)
-        if ws is None:
-            fn = self.lib.mtts_decoder_workspace_bytes if kind == "dec" else self.lib.mtts_encoder_workspace_bytes
-            n = fn(self.ctx, a, b)
-            if n < 0:
-                check(-1)
+        if ws is None or ws.numel() < n:
+            ws = None
+            self._ws.pop(key, None)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws
+
+    def workspace_bytes_held(self) -> int:
+        return sum(int(w.numel()) for w in self._ws.values())
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         if not t.is_cuda:
@@ -318,15 +355,33 @@ class HipModel:
                                             ws.numel(), stream_ptr()))
         return out
 
+    def fold_rows(self, y_max: int, align: int) -> int:
+        """Rows per utterance the folded estimator needs for valid lengths up to y_max (mtts_fold_rows)."""
+        n = self.lib.mtts_fold_rows(self.ctx, int(y_max), int(align))
+        if n < 0:
+            check(-1)
+        return n
+
     def cfm_solve(self, x0, mu, mask, t_span, solver: str, add_mu: bool = False, t_out: Optional[int] = None,
-                  out_scale: float = 1.0, out_shift: float = 0.0):
-        x0, mu, mask = self._f32(x0), self._f32(mu), self._f32(mask)
+                  out_scale: float = 1.0, out_shift: float = 0.0, y_lengths=None, y_max: Optional[int] = None,
+                  t_fold: Optional[int] = None):
+        """``y_lengths`` (int64 [B] on the device) + ``y_max`` + ``t_fold``: prefix masks on folded padding
+        (mtts_cfm_solve_folded; ``mask`` is then not read)."""
+        x0, mu = self._f32(x0), self._f32(mu)
         B, nf, T = x0.shape
         if solver not in SOLVERS:
             raise ValueError(f"unsupported solver {solver!r} (euler, midpoint, rk4)")
         ts = np.ascontiguousarray(torch.as_tensor(t_span).detach().to("cpu", torch.float32).numpy())
         t_out = T if t_out is None else int(t_out)
         out = torch.empty(B, nf, t_out, dtype=torch.float32, device=x0.device)
+        if t_fold is not None:
+            y_lengths = y_lengths.detach().to(torch.int64).contiguous()
+            ws = self._workspace("dec", B, int(t_fold))
+            check(self.lib.mtts_cfm_solve_folded(self.ctx, ptr(x0), ptr(mu), ptr(y_lengths), int(y_max), int(bool(add_mu)),
+                                                 ts.ctypes.data, len(ts) - 1, SOLVERS[solver], B, T, int(t_fold), ptr(out), t_out,
+                                                 float(out_scale), float(out_shift), ws.data_ptr(), ws.numel(), stream_ptr()))
+            return out
+        mask = self._f32(mask)
         ws = self._workspace("dec", B, T)
         check(self.lib.mtts_cfm_solve(self.ctx, ptr(x0), ptr(mu), ptr(mask), int(bool(add_mu)), ts.ctypes.data, len(ts) - 1,
                                       SOLVERS[solver], B, T, ptr(out), t_out, float(out_scale), float(out_shift),

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     const int q0 = qb * (NW * AT_QW) + wave * AT_QW;
     const int ld = 3 * p.H * p.D;
     const size_t rowbase = (size_t)b * p.T;
-    const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;      // keys of this utterance: [0, Tb) (per-request padding)
+    const int Tb = p.klen ? min(p.T, p.klen[b]) : p.T;      // keys of this utterance: [0, Tb) (per-request / folded padding)
     const float* qptr = p.qkv + head * p.D;
     const float* kptr = p.qkv + p.H * p.D + head * p.D;
     const float* vptr = p.qkv + 2 * p.H * p.D + head * p.D;

@@ -50,7 +50,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
     if (gn) {
         const int rows_w = BM / 2, row_w0 = m0 + wm * rows_w;             // T_out % rows_w == 0: one batch element per wave tile
         const int b = min(row_w0 / p.T_out, p.B - 1), t_w0 = row_w0 - b * p.T_out;      // (tail tiles past M: gn_rows = 0 below)
-        const int Tb = p.gn_tlen ? min(p.T_out, p.gn_tlen[b] >> p.gn_tshift) : p.T_out;
+        const int Tb = p.gn_nrows ? min(p.T_out, p.gn_nrows[b]) : p.T_out;
         gn_rows = row_w0 < M ? max(0, min(rows_w, Tb - t_w0)) : 0;
         const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
         const int cols0 = min(64, (g0 + 1) * cpg - n0w);

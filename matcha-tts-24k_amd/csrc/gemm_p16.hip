@@ -277,6 +277,15 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                 }
             }
             if (j == 0) {
+                if (live && p.gnr_nextra) {            // folded padding: nextra copies of the conv's bias row (closed form)
+                    const float ne = (float)p.gnr_nextra[b];
+                    if (ne > 0.f) {
+                        const float nb = ne * (float)cpg, delta = p.gnr_bias_stats[2 * g] - mean, nt = n + nb;
+                        mean += delta * (nb / nt);
+                        m2 += ne * p.gnr_bias_stats[2 * g + 1] + delta * delta * (n * nb / nt);
+                        n = nt;
+                    }
+                }
                 srow[gl] = mean;
                 srow[4 + gl] = n > 0.f ? 1.0f / sqrtf(m2 / n + p.gnr_eps) : 0.f;
             }
@@ -431,6 +440,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
         if (!a.gnr_stats || !a.gnr_gamma || !a.gnr_beta || !a.gnr_mask || a.gnr_groups <= 0 || a.gnr_tile_rows <= 0 || (a.N % a.gnr_groups) ||
             (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 3) || (a.N & 63) || !plain || (a.T_out % bm) || (a.T_out % a.gnr_tile_rows) || ln ||
+            ((a.gnr_nextra != nullptr) != (a.gnr_bias_stats != nullptr)) ||
             a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f)
             return hipErrorInvalidValue;
     }

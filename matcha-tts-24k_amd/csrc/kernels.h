@@ -74,8 +74,7 @@ struct GemmArgs {
     // T_out % (BM/2) == 0 (gemm_p16_wave_rows), N % 64 == 0 and an epilogue of bias only.
     float* gn_stats = nullptr;
     int gn_groups = 0;
-    const int* gn_tlen = nullptr;     // per-utterance frame limits (>> gn_tshift), as the GroupNorm kernels' tlen
-    int gn_tshift = 0;
+    const int* gn_nrows = nullptr;    // [B] rows of each utterance that enter the statistics (the GroupNorm kernels' nrows); null = T_out
     // Block1D tail in the epilogue (ResNet output, P16 kernel): c += Mish(GroupNorm(y)[row][n]) * gnr_mask[row], where y is the
     // second conv's fp32 output and its statistics are the tile entries that conv's epilogue left (gn_stats there): this GEMM
     // is the ResNet's 1x1 residual conv, so the sum is the ResNet output (reference decoder.py:58-63) and no gn_apply pass or
@@ -85,6 +84,8 @@ struct GemmArgs {
     int gnr_tile_rows = 0, gnr_groups = 0;
     const float* gnr_gamma = nullptr; const float* gnr_beta = nullptr; const float* gnr_mask = nullptr;
     float gnr_eps = 1e-5f;
+    const int* gnr_nextra = nullptr;      // folded padding (GnApplyArgs::nextra / bias_stats): copies of the producing conv's bias
+    const float* gnr_bias_stats = nullptr;//   row that belong to the statistics without existing as rows
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
@@ -128,8 +129,9 @@ struct AttnArgs {
     const _Float16* qkv16 = nullptr; int ld16 = 0;     // row stride in halves (>= 6*H*64)
     _Float16* out16 = nullptr; int ldo16 = 0;          // row stride in halves (>= 2*H*64)
     float out_lscale = 2048.0f;
-    const int* tlen = nullptr;    // [B] per-utterance frame limit (>> tshift): keys at or beyond it do not exist; null = T
-    int tshift = 0;
+    const int* klen = nullptr;    // [B] keys of utterance b are rows [0, klen[b]); null = T.  With folded padding `mask` holds the
+                                  // additive key bias itself: 1 for valid frames, ln(n_pad) for the one row that stands for n_pad
+                                  // identical padded frames (reference bias +0 each)
     bool fast16 = false;          // P16 I/O only: single fp16 product per MAC (no residual terms)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
@@ -169,9 +171,8 @@ static inline int gn_chunk_rows(int B, int T) {
 }
 static inline int gn_chunks(int B, int T) { const int r = gn_chunk_rows(B, T); return (T + r - 1) / r; }
 static inline int gn_chunks_max(int T) { return (T + GN_CHUNK_MIN - 1) / GN_CHUNK_MIN; }      // scratch sizing
-// tlen (optional, [B] int32): utterance b only has frames [0, tlen[b] >> tshift); statistics ignore the rest
-hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* tlen = nullptr,
-                             int tshift = 0);
+// nrows (optional, [B] int32): only frames [0, nrows[b]) of utterance b enter the statistics
+hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* nrows = nullptr);
 // out = Mish(GN(y)) ; out = (out [+ chbias[c]]) * mask[row] ; out += res[row][c]
 struct GnApplyArgs {
     const float* y = nullptr; const float* partial = nullptr;
@@ -184,8 +185,12 @@ struct GnApplyArgs {
     _Float16* out16 = nullptr;        // optional P16 copy of the output rows (C % 32 == 0), row stride ld16 halves; out may then be null
     int ld16 = 0;
     const float* out16_mask = nullptr;// [B*T] multiplies the out16 copy only
-    const int* tlen = nullptr;        // [B] per-utterance frame limit (>> tshift) for the statistics; null = T
-    int tshift = 0;
+    const int* nrows = nullptr;       // [B] rows of utterance b that enter the statistics; null = T
+    // Folded padding: the reference pads every utterance to the batch-wide length and GroupNorm counts those frames; beyond the
+    // first padded frame the conv output is exactly its bias row, so nextra[b] copies of that row enter the statistics in closed
+    // form: per group (mean of the bias, sum of squared deviations of ONE copy) = bias_stats[g][2], packed with the weights.
+    const int* nextra = nullptr;
+    const float* bias_stats = nullptr;
     int chunk_rows = 0;               // set by launch_gn_apply (gn_chunk_rows(B, T)), must match the partial pass
     const float* tile_stats = nullptr;// alternative to `partial`: the entries a P16 GEMM's epilogue left (GemmArgs::gn_stats)
     int tile_rows = 0;                // rows per wave tile of that GEMM (gemm_p16_wave_rows); T % tile_rows == 0
@@ -194,8 +199,9 @@ struct GnApplyArgs {
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 
 // channels-first [B,C,T] <-> channels-last [B,T,ld] moves
-// dst[b,t,col_off + c] = src[b,c,t] (+ add[b,c,t])
-hipError_t launch_cf_to_cl(const float* src, const float* add, int B, int C, int T, float* dst, int ld, int col_off, hipStream_t s);
+// dst[b*T + t, col_off + c] = src[b,c,t] (+ add[b,c,t]) for t < T; the source rows are T_src long (T_src = 0: T)
+hipError_t launch_cf_to_cl(const float* src, const float* add, int B, int C, int T, float* dst, int ld, int col_off, hipStream_t s,
+                           int T_src = 0);
 // dst[b,c,t] = src[b,t,c] * scale + shift for t < T_out
 hipError_t launch_cl_to_cf(const float* src, int ld, int B, int C, int T, float* dst, int T_out, float scale, float shift, hipStream_t s);
 hipError_t launch_fill_cols(float* dst, int M, int ld, int col0, int ncols, float v, hipStream_t s);
@@ -218,6 +224,24 @@ hipError_t launch_durations(const float* logw, const float* mask, float scale_co
                             int32_t* cum, int64_t* yfl, hipStream_t s);
 // level mask of the U-Net: dst[b, t] = src[b, t * stride], t < T_dst (reference decoder.py:390 mask[:, :, ::2])
 hipError_t launch_mask_down(const float* src, int B, int T_src, int stride, float* dst, int T_dst, hipStream_t s);
+// Per-level frame tables of one estimator call (norm_glue.hip).  Level l has T[l] rows per utterance.
+//  folded (y_len != null): the reference runs the estimator on T_true frames per utterance of which only the first y_len[b] are
+//    valid; all padded frames of a level are identical rows, so the folded layout keeps L_l = ceil(y_len / 2^l) valid
+//    rows + ONE row for the n_pad = (T_true >> l) - L_l padded ones:  mask = [t < L_l], kbias = 1 | ln(n_pad) at t = L_l,
+//    nrows = L_l + (n_pad > 0) (attention keys, GroupNorm rows), nextra = max(n_pad - 1, 0) (GroupNorm bias-row copies).
+//  unfolded (y_len == null, tlen != null; per-request padding): nrows = min(T[l], tlen[b] >> l), nextra = 0, masks untouched.
+//  tlen (optional, [B]): utterance b's own padded length T_true (per-request padding); else T_true for all.
+struct FrameTableArgs {
+    const int64_t* y_len = nullptr;
+    const int* tlen = nullptr;
+    int B = 0, T_true = 0, nl = 0;
+    int T[4] = {0, 0, 0, 0};
+    float* mask[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* kbias[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* nrows[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* nextra[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+hipError_t launch_frame_tables(const FrameTableArgs& a, hipStream_t s);
 hipError_t launch_align_pool(const float* mu_x, const int32_t* cum, const int64_t* yfl, int B, int nf, int Tx, int T_pad,
                              float* mu_y, float* y_mask, int64_t* y_len, hipStream_t s);
 

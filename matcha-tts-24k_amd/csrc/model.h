@@ -26,6 +26,7 @@ struct Vec { size_t off = 0; int n = 0; };
 struct ResnetW {
     Panel conv1, conv2, res;
     Vec gn1_g, gn1_b, gn2_g, gn2_b;
+    Vec gn1_bs, gn2_bs;       // per GroupNorm group (mean, sum of squared deviations) of conv1's / conv2's bias row (folded padding)
     int cin = 0, cout = 0;
     int tb_off = 0;           // column offset of this block's time bias inside the per-evaluation bias row
 };
@@ -43,7 +44,7 @@ struct DecW {
     std::vector<Panel> up_even, up_odd;  // ConvTranspose phases (levels-1 entries)
     Panel up_last;                       // k3 conv of the last up block
     Panel final_conv, final_proj;
-    Vec fgn_g, fgn_b;
+    Vec fgn_g, fgn_b, fgn_bs;
 };
 struct EncW {
     Vec emb, spk_enc, spk_dur, rope_cos, rope_sin;

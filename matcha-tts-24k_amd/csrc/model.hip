@@ -109,6 +109,24 @@ struct Packer {
         std::memcpy(&c->image[v.off], t->data(), n * sizeof(float));
         return v;
     }
+    // Folded padding (kernels.h GnApplyArgs::bias_stats): where every input tap of a conv is a masked (zero) frame its output
+    // row is exactly the bias, so any number of such rows enters the following GroupNorm in closed form from, per group,
+    // (mean of the bias, sum of squared deviations from that mean), computed here in double.
+    Vec bias_group_stats(const Panel& p, int G) {
+        Vec v;
+        v.off = alloc(2 * G);
+        v.n = 2 * G;
+        const int cpg = p.N / G;
+        for (int g = 0; g < G; ++g) {
+            double m = 0.0, q = 0.0;
+            for (int k = 0; k < cpg; ++k) m += p.has_bias ? (double)c->image[p.b + g * cpg + k] : 0.0;
+            m /= cpg;
+            for (int k = 0; k < cpg; ++k) { const double d = (p.has_bias ? (double)c->image[p.b + g * cpg + k] : 0.0) - m; q += d * d; }
+            c->image[v.off + 2 * g] = (float)m;
+            c->image[v.off + 2 * g + 1] = (float)q;
+        }
+        return v;
+    }
     // kind 0 Linear [N,C]; 1 Conv1d [N,C,ntaps]; 2 ConvTranspose1d [C,N,kT] with taps tsel
     Panel panel(const std::string& wkey, const std::string& bkey, int kind, int N, int C, int ntaps, int kT = 0,
                 const int* tsel = nullptr, const std::vector<float>* col_scale = nullptr,
@@ -260,6 +278,7 @@ static int pack_all(mtts_ctx* c) {
         r.gn2_g = P.vec(p + "block2.block.1.weight", co);
         r.gn2_b = P.vec(p + "block2.block.1.bias", co);
         r.res = P.panel(p + "res_conv.weight", p + "res_conv.bias", 1, co, ci, 1);
+        if (P.ok) { r.gn1_bs = P.bias_group_stats(r.conv1, 8); r.gn2_bs = P.bias_group_stats(r.conv2, 8); }
         mlp_w.push_back(p + "mlp.1.weight");
         mlp_b.push_back(p + "mlp.1.bias");
         mlp_n.push_back(co);
@@ -315,6 +334,7 @@ static int pack_all(mtts_ctx* c) {
     D.fgn_g = P.vec(R + "final_block.block.1.weight", cfin);
     D.fgn_b = P.vec(R + "final_block.block.1.bias", cfin);
     D.final_proj = P.panel(R + "final_proj.weight", R + "final_proj.bias", 1, g.n_feats, cfin, 1);
+    if (P.ok) D.fgn_bs = P.bias_group_stats(D.final_conv, 8);
     // per-ResNet Linear(Mish(t)) stacked into one [sum(cout), temb] panel (rows of different blocks may differ in count)
     {
         int total = 0;
@@ -388,6 +408,15 @@ struct DecBufs {
     float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
     float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
     int ldx = 0, ldv = 0;
+    // frame tables (kernels.h FrameTableArgs), per level: null when every utterance owns all T rows
+    int T_true = 0;                      // the reference's padded length; T above is the rows per utterance actually held
+    bool folded = false;
+    std::vector<int*> nrows, nextra;     // rows in the statistics / attention keys; closed-form bias-row copies
+    std::vector<float*> kbias;           // additive attention key bias (= mask when not folded)
+    const int* nr(int l) const { return tables ? nrows[l] : nullptr; }
+    const int* ne(int l) const { return folded ? nextra[l] : nullptr; }
+    const float* kb(int l) const { return folded ? kbias[l] : mask[l]; }
+    bool tables = false;
 };
 
 // Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
@@ -418,10 +447,14 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     const size_t M0 = (size_t)B * T;
     d.Tl.resize(d.nl);
     d.mask.resize(d.nl); d.bufA.resize(d.nl); d.bufB.resize(d.nl); d.skip.resize(d.nl);
+    d.nrows.resize(d.nl); d.nextra.resize(d.nl); d.kbias.resize(d.nl);
     for (int l = 0; l < d.nl; ++l) {
         d.Tl[l] = T >> l;
         const size_t Ml = (size_t)B * d.Tl[l];
         d.mask[l] = ws.f(Ml);
+        d.kbias[l] = ws.f(Ml);
+        d.nrows[l] = reinterpret_cast<int*>(ws.f(B));
+        d.nextra[l] = reinterpret_cast<int*>(ws.f(B));
         d.bufA[l] = ws.f(Ml * cmax);
         d.bufB[l] = ws.f(Ml * cmax);
         d.skip[l] = ws.f(Ml * cmax);
@@ -490,23 +523,25 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
     a.a0 = in0; a.lda0 = ld0; a.c0 = c0; a.a1 = in1; a.lda1 = ld1; a.c1 = c1; a.a_mask = mask;
     a.out = d.Y; a.ldc = C;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, d.nr(lvl)));
     GnApplyArgs g1;
-    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.tlen = c->d_tlen; g1.tshift = lvl;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.nrows = d.nr(lvl);
+    if (d.folded) { g1.nextra = d.ne(lvl); g1.bias_stats = W(c, r.gn1_bs.off); }
     g1.chbias = tbias; g1.out = d.Hh; g1.B = B; g1.T = T; g1.C = C;
     LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a0 = d.Hh; b.lda0 = C; b.c0 = C; b.out = d.Y; b.ldc = C;      // Hh is already masked
     RET_IF(run_gemm(c, b, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, d.nr(lvl)));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a0 = in0; rc.lda0 = ld0; rc.c0 = c0; rc.a1 = in1; rc.lda1 = ld1; rc.c1 = c1; rc.a_mask = mask;
     rc.out = d.Rr; rc.ldc = C;
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
-    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.nrows = d.nr(lvl);
+    if (d.folded) { g2.nextra = d.ne(lvl); g2.bias_stats = W(c, r.gn2_bs.off); }
     g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
     if (emit_stats && (C % 64) == 0) {       // for the first transformer block: LayerNorm moments and, in P16 mode, x's image
         g2.stats_out = d.lnp;
@@ -539,9 +574,9 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         q.out16 = QKV16; q.ld16 = 6 * inner; q.out_lscale = 1.0f;
         RET_IF(run_gemm(c, q, s));
         AttnArgs at;
-        at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.mask[lvl];
+        at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.kb(lvl);
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl; at.fast16 = c->fast16;
+        at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.klen = d.nr(lvl); at.fast16 = c->fast16;
         RET_IF(run_attn(c, at, s));
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -575,8 +610,8 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
     }
     RET_IF(run_gemm(c, q, s));
     AttnArgs at;
-    at.qkv = d.QKV; at.mask = d.mask[lvl]; at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
-    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.tlen = c->d_tlen; at.tshift = lvl; at.fast16 = c->fast16;
+    at.qkv = d.QKV; at.mask = d.kb(lvl); at.out = d.ATT; at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
+    at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.klen = d.nr(lvl); at.fast16 = c->fast16;
     RET_IF(run_attn(c, at, s));
     GemmArgs o;
     panel_args(c, t.out, o); rows_plain(o, B, T);
@@ -685,9 +720,10 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a0 = cur; a.lda0 = cur_ld; a.c0 = C0; a.a_mask = d.mask[0]; a.out = d.Y; a.ldc = C0;
     RET_IF(run_gemm(c, a, s));
-    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
+    LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, d.nr(0)));
     GnApplyArgs ga;
-    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.tlen = c->d_tlen;
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.nrows = d.nr(0);
+    if (d.folded) { ga.nextra = d.ne(0); ga.bias_stats = W(c, D.fgn_bs.off); }
     ga.out = d.Hh; ga.B = B; ga.T = T; ga.C = C0;
     LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
     GemmArgs p;
@@ -720,21 +756,22 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     a.a16_0 = in0; a.lda16_0 = 2 * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = 2 * c1; a.c1 = c1;
     a.out = d.Y; a.ldc = C;
     const int fr1 = gn_fuse_rows(a, C, 8, T);
-    if (fr1) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_tlen = c->d_tlen; a.gn_tshift = lvl; }
+    if (fr1) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_nrows = d.nr(lvl); }
     RET_IF(run_gemm(c, a, s));
-    if (!fr1) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    if (!fr1) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, d.nr(lvl)));
     GnApplyArgs g1;
     if (fr1) { g1.tile_stats = d.gns; g1.tile_rows = fr1; }
-    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.tlen = c->d_tlen; g1.tshift = lvl;
+    g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.nrows = d.nr(lvl);
+    if (d.folded) { g1.nextra = d.ne(lvl); g1.bias_stats = W(c, r.gn1_bs.off); }
     g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
     LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
     const int fr2 = gn_fuse_rows(b, C, 8, T);
-    if (fr2) { b.gn_stats = d.gns; b.gn_groups = 8; b.gn_tlen = c->d_tlen; b.gn_tshift = lvl; }
+    if (fr2) { b.gn_stats = d.gns; b.gn_groups = 8; b.gn_nrows = d.nr(lvl); }
     RET_IF(run_gemm(c, b, s));
-    if (!fr2) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, c->d_tlen, lvl));
+    if (!fr2) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, d.nr(lvl)));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
     rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
@@ -745,6 +782,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
         // statistics conv2 left, and writes x's image + LayerNorm moments -- no gn_apply pass, no residual round trip.
         rc.gnr_y = d.Y; rc.gnr_stats = d.gns; rc.gnr_tile_rows = fr2; rc.gnr_groups = 8;
         rc.gnr_gamma = W(c, r.gn2_g.off); rc.gnr_beta = W(c, r.gn2_b.off); rc.gnr_mask = mask;
+        if (d.folded) { rc.gnr_nextra = d.ne(lvl); rc.gnr_bias_stats = W(c, r.gn2_bs.off); }
         rc.out16 = d.X16; rc.ld16 = 2 * C; rc.stats_out = d.lnp;
         RET_IF(run_gemm(c, rc, s));
         return 0;
@@ -753,7 +791,8 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     RET_IF(run_gemm(c, rc, s));
     GnApplyArgs g2;
     if (fr2) { g2.tile_stats = d.gns; g2.tile_rows = fr2; }
-    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.tlen = c->d_tlen; g2.tshift = lvl;
+    g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.nrows = d.nr(lvl);
+    if (d.folded) { g2.nextra = d.ne(lvl); g2.bias_stats = W(c, r.gn2_bs.off); }
     g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;
     g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
     LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
@@ -840,12 +879,13 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
     a.a16_0 = cur; a.lda16_0 = 2 * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
     const int frf = gn_fuse_rows(a, C0, 8, T);
-    if (frf) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_tlen = c->d_tlen; a.gn_tshift = 0; }
+    if (frf) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_nrows = d.nr(0); }
     RET_IF(run_gemm(c, a, s));
-    if (!frf) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, c->d_tlen, 0));
+    if (!frf) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C0, 8, d.gnp, s, d.nr(0)));
     GnApplyArgs ga;
     if (frf) { ga.tile_stats = d.gns; ga.tile_rows = frf; }
-    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.tlen = c->d_tlen;
+    ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.nrows = d.nr(0);
+    if (d.folded) { ga.nextra = d.ne(0); ga.bias_stats = W(c, D.fgn_bs.off); }
     ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
     LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
     GemmArgs p;
@@ -856,9 +896,24 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     return 0;
 }
 
-static int build_masks(mtts_ctx* c, DecBufs& d, const float* mask, hipStream_t s) {
-    for (int l = 0; l < d.nl; ++l)
-        LAUNCH(c, 2, 0, s, launch_mask_down(mask, d.B, d.T, 1 << l, d.mask[l], d.Tl[l], s));
+// Level masks and frame tables of one call.  y_len == null: any float mask [B, T] (reference decoder.py:390 mask[:, :, ::2]),
+// every utterance owns its T rows (or tlen[b] of them: per-request padding).  y_len != null: prefix masks of y_len[b] frames in
+// the folded layout -- d.T rows per utterance stand for T_true reference frames (FrameTableArgs).
+static int build_frames(mtts_ctx* c, DecBufs& d, const float* mask, const int64_t* y_len, int T_true, hipStream_t s) {
+    d.T_true = T_true;
+    d.folded = y_len != nullptr;
+    d.tables = d.folded || c->d_tlen != nullptr;
+    if (!d.folded)
+        for (int l = 0; l < d.nl; ++l)
+            LAUNCH(c, 2, 0, s, launch_mask_down(mask, d.B, d.T, 1 << l, d.mask[l], d.Tl[l], s));
+    if (d.tables) {
+        FrameTableArgs f;
+        f.y_len = y_len; f.tlen = c->d_tlen; f.B = d.B; f.T_true = T_true; f.nl = d.nl;
+        for (int l = 0; l < d.nl; ++l) {
+            f.T[l] = d.Tl[l]; f.mask[l] = d.mask[l]; f.kbias[l] = d.kbias[l]; f.nrows[l] = d.nrows[l]; f.nextra[l] = d.nextra[l];
+        }
+        LAUNCH(c, 2, 0, s, launch_frame_tables(f, s));
+    }
     return 0;
 }
 
@@ -954,7 +1009,7 @@ int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, con
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
     const int nf = c->cfg.n_feats;
-    RET_IF(build_masks(c, d, d_mask, s));
+    RET_IF(build_frames(c, d, d_mask, nullptr, T, s));
     LAUNCH(c, 2, 0, s, launch_fill_cols(d.xmu, B * T, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
     LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_x, nullptr, B, nf, T, d.xmu, d.ldx, 0, s));
     LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mu, nullptr, B, nf, T, d.xmu, d.ldx, nf, s));
@@ -967,28 +1022,31 @@ int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, con
     return 0;
 }
 
-int mtts_cfm_solve(mtts_ctx* c, const float* d_x0, const float* d_mu, const float* d_mask, int add_mu, const float* h_t_span,
-                   int n_steps, int solver, int B, int T, float* d_out, int T_out, float out_scale, float out_shift, void* d_ws,
-                   int64_t ws_bytes, void* stream) {
+// BASECFM.solve (reference flow_matching.py:60-63) + torchdiffeq's fixed-grid loop.  The inputs are [B, n_feats, T_src]; the
+// estimator holds T <= T_src rows per utterance (T < T_src: folded padding, y_len gives the prefix masks; else d_mask).
+static int solve_core(mtts_ctx* c, const float* d_x0, const float* d_mu, const float* d_mask, const int64_t* d_y_len, int add_mu,
+                      const float* h_t_span, int n_steps, int solver, int B, int T_src, int T, float* d_out, int T_out, float out_scale,
+                      float out_shift, void* d_ws, int64_t ws_bytes, void* stream) {
     RET_IF(check_ready(c));
     if (!h_t_span || n_steps < 1) { set_error("mtts_cfm_solve: bad time grid"); return -1; }
     const int stages = solver == MTTS_SOLVER_EULER ? 1 : solver == MTTS_SOLVER_MIDPOINT ? 2 : solver == MTTS_SOLVER_RK4 ? 4 : 0;
     if (!stages) { set_error("unsupported solver"); return -1; }
     if (n_steps * stages > MAX_EVALS) { set_error("too many function evaluations in one solve (max 256)"); return -1; }
+    if (T_out > T) { set_error("mtts_cfm_solve: T_out exceeds the rows held per utterance"); return -1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     WS ws(d_ws, (size_t)ws_bytes);
     DecBufs d;
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
     const int nf = c->cfg.n_feats, M = B * T;
-    RET_IF(build_masks(c, d, d_mask, s));
+    RET_IF(build_frames(c, d, d_mask, d_y_len, T_src, s));
     // state rows: x | mu | zero pad.  z = mu + noise when use_mu_prior (reference flow_matching.py:52-55)
     float* states[2] = {d.xmu, d.xmu2};
     for (int k = 0; k < (stages > 1 ? 2 : 1); ++k) {
         LAUNCH(c, 2, 0, s, launch_fill_cols(states[k], M, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
-        LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mu, nullptr, B, nf, T, states[k], d.ldx, nf, s));
+        LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_mu, nullptr, B, nf, T, states[k], d.ldx, nf, s, T_src));
     }
-    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_x0, add_mu ? d_mu : nullptr, B, nf, T, d.xmu, d.ldx, 0, s));
+    LAUNCH(c, 2, 0, s, launch_cf_to_cl(d_x0, add_mu ? d_mu : nullptr, B, nf, T, d.xmu, d.ldx, 0, s, T_src));
 
     // evaluation times in torchdiffeq's fp32 arithmetic (fixed grid = t_span)
     TimeVals tv;
@@ -1026,6 +1084,33 @@ int mtts_cfm_solve(mtts_ctx* c, const float* d_x0, const float* d_mu, const floa
     }
     LAUNCH(c, 2, 0, s, launch_cl_to_cf(d.xmu, d.ldx, B, nf, T, d_out, T_out, out_scale, out_shift, s));
     return 0;
+}
+
+int mtts_cfm_solve(mtts_ctx* c, const float* d_x0, const float* d_mu, const float* d_mask, int add_mu, const float* h_t_span,
+                   int n_steps, int solver, int B, int T, float* d_out, int T_out, float out_scale, float out_shift, void* d_ws,
+                   int64_t ws_bytes, void* stream) {
+    if (!d_mask) { set_error("mtts_cfm_solve: null mask"); return -1; }
+    return solve_core(c, d_x0, d_mu, d_mask, nullptr, add_mu, h_t_span, n_steps, solver, B, T, T, d_out, T_out, out_scale, out_shift,
+                      d_ws, ws_bytes, stream);
+}
+
+int mtts_fold_rows(mtts_ctx* c, int y_max, int align) {
+    if (!c || y_max < 1 || align < 1) { set_error("mtts_fold_rows: bad argument"); return -1; }
+    const int f = 1 << (c->cfg.dec_levels - 1);
+    return round_up((y_max + f - 1) / f + 1, align) * f;
+}
+
+int mtts_cfm_solve_folded(mtts_ctx* c, const float* d_x0, const float* d_mu, const int64_t* d_y_lengths, int y_max, int add_mu,
+                          const float* h_t_span, int n_steps, int solver, int B, int T, int T_fold, float* d_out, int T_out,
+                          float out_scale, float out_shift, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (!c || !d_y_lengths) { set_error("mtts_cfm_solve_folded: bad argument"); return -1; }
+    if (T_fold > T || T_fold < mtts_fold_rows(c, y_max, 1)) {
+        set_error("mtts_cfm_solve_folded: T_fold must hold ceil(y_max / 2^l) + 1 rows at every level and not exceed T (mtts_fold_rows)");
+        return -1;
+    }
+    if (y_max >= T) { set_error("mtts_cfm_solve_folded: no padded frame to fold (y_max >= T)"); return -1; }
+    return solve_core(c, d_x0, d_mu, nullptr, d_y_lengths, add_mu, h_t_span, n_steps, solver, B, T, T_fold, d_out, T_out, out_scale,
+                      out_shift, d_ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ text encoder

@@ -118,13 +118,13 @@ hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
 // (Chan et al.) and applies GN affine -> Mish -> mask [-> + time bias -> mask] [-> + residual].
 // Block shape: x = C/4 float4 columns, y = RT row lanes.
 __global__ void gn_partial_kernel(const float* __restrict__ y, int T, int C, int G, float* __restrict__ partial,
-                                  const int* __restrict__ tlen, int tshift, int chunk_rows) {
+                                  const int* __restrict__ nrows, int chunk_rows) {
     extern __shared__ float red[];                 // [blockDim.x*blockDim.y] + [G]
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int c4 = threadIdx.x, ry = threadIdx.y, RT = blockDim.y, nth = blockDim.x * blockDim.y;
     const int tid = ry * blockDim.x + c4;
     const int t0 = chunk * chunk_rows;
-    const int Tb = tlen ? min(T, tlen[b] >> tshift) : T;       // this utterance's own length (per-request padding)
+    const int Tb = nrows ? min(T, nrows[b]) : T;               // this utterance's own rows (per-request / folded padding)
     const int rows = max(0, min(chunk_rows, Tb - t0));
     const int cpg4 = (C / G) / 4;                  // float4 columns per group
     const float* base = y + ((size_t)b * T + t0) * C + c4 * 4;
@@ -206,11 +206,11 @@ static inline dim3 gn_block(int C) {
     return dim3(c4, rt);
 }
 
-hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* tlen, int tshift) {
+hipError_t launch_gn_partial(const float* y, int B, int T, int C, int G, float* partial, hipStream_t s, const int* nrows) {
     if (!y || !partial || B <= 0 || T <= 0 || !gn_shape_ok(C, G)) return hipErrorInvalidValue;
     const dim3 blk = gn_block(C);
     const size_t lds = (size_t)(blk.x * blk.y + G) * sizeof(float);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(B, T), B), blk, lds, s, y, T, C, G, partial, tlen, tshift, gn_chunk_rows(B, T));
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_chunks(B, T), B), blk, lds, s, y, T, C, G, partial, nrows, gn_chunk_rows(B, T));
     return hipGetLastError();
 }
 
@@ -255,7 +255,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
                 n = nt;
             }
         } else if (g < p.G) {
-            const int Tb = p.tlen ? min(p.T, p.tlen[b] >> p.tshift) : p.T;
+            const int Tb = p.nrows ? min(p.T, p.nrows[b]) : p.T;
             for (int k = j; k < nchunks; k += L) {
                 const int rows_k = min(p.chunk_rows, Tb - k * p.chunk_rows);
                 if (rows_k <= 0) break;
@@ -282,6 +282,15 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
             }
         }
         if (g < p.G && j == 0) {
+            if (p.nextra) {                            // folded padding: nextra copies of the conv's bias row, in closed form
+                const float ne = (float)p.nextra[b];
+                if (ne > 0.f) {
+                    const float nb = ne * (float)cpg, delta = p.bias_stats[2 * g] - mean, nt = n + nb;
+                    mean += delta * (nb / nt);
+                    m2 += ne * p.bias_stats[2 * g + 1] + delta * delta * (n * nb / nt);
+                    n = nt;
+                }
+            }
             smean[g] = mean;
             srstd[g] = 1.0f / sqrtf(m2 / n + p.eps);
         }
@@ -358,6 +367,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
     if (a.out16 && ((a.C & 31) || a.ld16 < 2 * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.tile_stats && (a.tile_rows <= 0 || (a.T % a.tile_rows) || (a.C & 63) || (a.C / a.G) < 32)) return hipErrorInvalidValue;
+    if ((a.nextra != nullptr) != (a.bias_stats != nullptr)) return hipErrorInvalidValue;
     GnApplyArgs b = a;
     b.chunk_rows = gn_chunk_rows(a.B, a.T);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_chunks(a.B, a.T), a.B), gn_block(a.C), 0, s, b);
@@ -366,7 +376,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ layout moves
 // dst[b, t, col_off + c] = src[b, c, t] (+ add[b, c, t])        [B,C,T] -> rows of [B*T, ld]
-__global__ void cf_to_cl_kernel(const float* __restrict__ src, const float* __restrict__ add, int C, int T,
+__global__ void cf_to_cl_kernel(const float* __restrict__ src, const float* __restrict__ add, int C, int T, int T_src,
                                 float* __restrict__ dst, int ld, int col_off) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -376,7 +386,7 @@ __global__ void cf_to_cl_kernel(const float* __restrict__ src, const float* __re
         const int c = c0 + ty + 8 * k, t = t0 + tx;
         float v = 0.f;
         if (c < C && t < T) {
-            const size_t i = ((size_t)b * C + c) * T + t;
+            const size_t i = ((size_t)b * C + c) * T_src + t;
             v = src[i];
             if (add) v += add[i];
         }
@@ -389,9 +399,11 @@ __global__ void cf_to_cl_kernel(const float* __restrict__ src, const float* __re
         if (c < C && t < T) dst[((size_t)b * T + t) * ld + col_off + c] = tile[tx][ty + 8 * k];
     }
 }
-hipError_t launch_cf_to_cl(const float* src, const float* add, int B, int C, int T, float* dst, int ld, int col_off, hipStream_t s) {
-    if (!src || !dst || B <= 0 || C <= 0 || T <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cf_to_cl_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(32, 8), 0, s, src, add, C, T, dst, ld, col_off);
+hipError_t launch_cf_to_cl(const float* src, const float* add, int B, int C, int T, float* dst, int ld, int col_off, hipStream_t s,
+                           int T_src) {
+    if (T_src == 0) T_src = T;
+    if (!src || !dst || B <= 0 || C <= 0 || T <= 0 || T_src < T) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cf_to_cl_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(32, 8), 0, s, src, add, C, T, T_src, dst, ld, col_off);
     return hipGetLastError();
 }
 
@@ -531,6 +543,49 @@ __global__ void mask_down_kernel(const float* __restrict__ src, int T_src, int s
 hipError_t launch_mask_down(const float* src, int B, int T_src, int stride, float* dst, int T_dst, hipStream_t s) {
     if (!src || !dst || B <= 0 || T_dst <= 0 || (size_t)(T_dst - 1) * stride >= (size_t)T_src) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mask_down_kernel, dim3((T_dst + 255) / 256, B), dim3(256), 0, s, src, T_src, stride, dst, T_dst);
+    return hipGetLastError();
+}
+
+// Per-level frame tables (kernels.h FrameTableArgs): one thread per (utterance, frame of level 0); levels walked in the thread.
+__global__ void frame_tables_kernel(const FrameTableArgs p) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t_true = p.tlen ? p.tlen[b] : p.T_true;
+    if (!p.y_len) {                                   // unfolded, per-request padding: only the row counts
+        if (t == 0)
+            for (int l = 0; l < p.nl; ++l) {
+                p.nrows[l][b] = min(p.T[l], t_true >> l);
+                p.nextra[l][b] = 0;
+            }
+        return;
+    }
+    int L = (int)min((int64_t)p.y_len[b], (int64_t)(1 << 30));
+    L = max(L, 0);
+    for (int l = 0; l < p.nl; ++l) {
+        if (l) L = (L + 1) >> 1;                      // mask[:, :, ::2] of a prefix mask (reference decoder.py:390)
+        const int Tl = p.T[l];
+        const int Lc = min(L, Tl);                    // (the host sized T[l] >= L + 1 whenever padded frames exist)
+        const int npad = max((t_true >> l) - Lc, 0);
+        const int rows = min(Lc + (npad > 0 ? 1 : 0), Tl);
+        if (t == 0) {
+            p.nrows[l][b] = rows;
+            p.nextra[l][b] = max(npad - 1, 0);
+        }
+        if (t < Tl) {
+            p.mask[l][(size_t)b * Tl + t] = t < Lc ? 1.0f : 0.0f;
+            p.kbias[l][(size_t)b * Tl + t] = t < Lc ? 1.0f : ((t == Lc && npad > 0) ? logf((float)npad) : 0.0f);
+        }
+    }
+}
+hipError_t launch_frame_tables(const FrameTableArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.nl < 1 || a.nl > 4 || a.T_true <= 0) return hipErrorInvalidValue;
+    for (int l = 0; l < a.nl; ++l) {
+        if (a.T[l] <= 0 || !a.nrows[l] || !a.nextra[l]) return hipErrorInvalidValue;
+        if (a.y_len && (!a.mask[l] || !a.kbias[l])) return hipErrorInvalidValue;
+    }
+    if (!a.y_len && !a.tlen) return hipErrorInvalidValue;
+    const int T0 = a.y_len ? a.T[0] : 1;
+    hipLaunchKernelGGL(frame_tables_kernel, dim3((T0 + 255) / 256, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -141,7 +141,7 @@ class MatchaTTSInfer(nn.Module):
                 raise ValueError("per_request_padding needs no batch-wide length: do not combine it with sync_max")
             t_len = [fix_len_compatibility(max(int(v), 1)) for v in y_fine_lengths.tolist()]
         mel = self.decoder(mu_y, y_mask, n_timesteps, z=z, t_out=y_max_length, out_scale=self._rt.mel_std,
-                           out_shift=self._rt.mel_mean, t_len=t_len)
+                           out_shift=self._rt.mel_mean, t_len=t_len, y_lengths=y_lengths, y_max=y_max_length)
         if not debug:
             return {"mel": mel, "mel_lengths": y_lengths}
         encoder_mel = mu_y[:, :, :y_max_length] * self._rt.mel_std + self._rt.mel_mean
@@ -210,44 +210,59 @@ def load_vocoder(vocoder_name, checkpoint=None, state_dict=None):
     return vocoder
 
 
-def to_waveform(mel, vocoder):
-    """reference inference.py:260-265."""
+def _waveform_on_device(mel, vocoder):
+    """Vocoder + peak normalisation of reference inference.py:260-264, left on the device."""
     audio = vocoder(mel)
     max_abs = audio.abs().max()
     if max_abs > 1.0:
         audio = audio / max_abs * 0.95
-    return audio.cpu().squeeze()
+    return audio
+
+
+def to_waveform(mel, vocoder):
+    """reference inference.py:260-265."""
+    return _waveform_on_device(mel, vocoder).cpu().squeeze()
 
 
 def trim_trailing_silence(audio, silence_threshold_db=-60.0):
-    """reference inference.py:268-287: drop trailing 10 ms windows whose RMS is under the threshold."""
+    """reference inference.py:268-287, window for window: 10 ms windows anchored at sample 0 (the ``len % window`` remainder is
+    never examined), RMS per window, count the run of trailing windows with ``rms < threshold`` (strict; a NaN window stops the
+    run as in the reference's loop), drop ``count * window`` samples from the END of the signal.  All full windows may go.
+    Works on a 1-D tensor on any device: the window RMS and the run length are computed where the audio lives (one scalar
+    comes back to the host), so ``pipeline`` trims before the device-to-host copy."""
     win = int(0.01 * SAMPLE_RATE)
-    thr = 10.0 ** (silence_threshold_db / 20.0)
-    n = audio.shape[-1]
-    end = n
-    while end > win:
-        seg = audio[..., end - win:end]
-        if float(torch.sqrt(torch.mean(seg.float() ** 2))) > thr:
-            break
-        end -= win
-    return audio[..., :end]
+    thr = 10 ** (silence_threshold_db / 20.0)
+    n_full = len(audio) // win
+    if n_full == 0:
+        return audio
+    rms = audio[: n_full * win].reshape(n_full, win).pow(2).mean(dim=1).sqrt()
+    loud = torch.logical_not(rms < thr)
+    idx = torch.arange(1, n_full + 1, device=audio.device)
+    last_loud = int((loud * idx).max())            # 1-based index of the last window that is not silent; 0 = none
+    trim = (n_full - last_loud) * win
+    if trim == 0:
+        return audio
+    return audio[:-trim]
 
 
 @torch.inference_mode()
 def pipeline(model, vocoder, text, speaker=0, voice_mix=None, n_timesteps=DEFAULT_NUM_STEPS, scale_correction=1.0,
              length_scale=1.0, debug=False):
-    """reference inference.py:233-257."""
+    """reference inference.py:233-257.  The reference wraps ``synthesise`` in ``torch.autocast`` (fp16 on its CUDA device);
+    here the estimator's arithmetic is chosen when the model is created (``MTTS_GEMM_TERMS``: default fp32-equivalent; 1 = fp16
+    operands / fp32 accumulate, the autocast arithmetic), not per call.  The trailing-silence trim runs on the device."""
     primary = voice_mix[0][0] if voice_mix is not None else speaker
     language = next(v["lang"] for v in VOICES if v["id"] == str(primary))
     tp = process_text(text, language)
     out = model.synthesise(tp["x"], tp["x_lengths"], n_timesteps=n_timesteps, speaker=speaker, voice_mix=voice_mix,
                            scale_correction=scale_correction, length_scale=length_scale, debug=debug)
+    waveform = trim_trailing_silence(_waveform_on_device(out["mel"], vocoder).squeeze()).cpu()
     if not debug:
-        return trim_trailing_silence(to_waveform(out["mel"], vocoder))
+        return waveform
     durs = out["phoneme_durations"].squeeze(0).tolist()
     raws = out["raw_phoneme_durations"].squeeze(0).tolist()
     pairs = list(zip(tp["x_phones"], raws, durs))
-    return (trim_trailing_silence(to_waveform(out["mel"], vocoder)), to_waveform(out["encoder_mel"], vocoder), pairs)
+    return waveform, to_waveform(out["encoder_mel"], vocoder), pairs
 
 
 def convert_to_mp3(waveform):  # pragma: no cover - post-waveform codec, out of the path's scope

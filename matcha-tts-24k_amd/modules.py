@@ -7,6 +7,7 @@ the HIP library through one shared ``HipModel``.  There is no PyTorch arithmetic
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -102,6 +103,8 @@ class CFM(nn.Module):
         self.solver = hp.solver
         self.sigma_min = hp.sigma_min
         self.use_mu_prior = hp.use_mu_prior
+        self.fold_padding = os.environ.get("MTTS_FOLD", "1") != "0"
+        self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "32"))
         object.__setattr__(self, "_rt", rt)
         self.estimator = Estimator()
         self.estimator._bind(rt)
@@ -125,22 +128,35 @@ class CFM(nn.Module):
             z[b:b + 1, :, :t] = self.noise(like[b:b + 1, :, :t])
         return z
 
+    def fold_plan(self, T: int, y_max: Optional[int]) -> Optional[int]:
+        """Rows per utterance for the folded estimator (include/mtts.h mtts_cfm_solve_folded), or None to run all T frames.
+        ``fold_padding`` (attribute; env MTTS_FOLD=0 turns the default off) and ``fold_align`` (MTTS_FOLD_ALIGN, default 32:
+        whole wave tiles per utterance at every level) are plain attributes like ``solver``."""
+        if not self.fold_padding or y_max is None:
+            return None
+        t_fold = self._rt.ready().fold_rows(y_max, self.fold_align)
+        return t_fold if t_fold < T else None
+
     @torch.inference_mode()
     def forward(self, mu, mask, n_timesteps, z: Optional[torch.Tensor] = None, t_out: Optional[int] = None,
-                out_scale: float = 1.0, out_shift: float = 0.0, t_len=None):
+                out_scale: float = 1.0, out_shift: float = 0.0, t_len=None, y_lengths=None, y_max: Optional[int] = None):
         """``z``: optional explicit noise (e.g. the CPU-generator stream for parity with the CPU reference).
-        ``t_len``: per-utterance padded lengths (list of even ints) for per-request padding (mtts_set_frame_limits)."""
+        ``t_len``: per-utterance padded lengths (list of even ints) for per-request padding (mtts_set_frame_limits).
+        ``y_lengths`` (LongTensor[B] on the device) + ``y_max`` (their maximum, on the host): ``mask`` is the prefix mask of
+        these lengths, which lets the estimator fold the padded frames (``fold_plan``); results equal the unfolded call."""
         hip = self._rt.ready()
         if z is None:
             z = self.noise(mu) if t_len is None else self.noise_per_request(mu, t_len)
         t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
+        kw = dict(add_mu=self.use_mu_prior, t_out=t_out, out_scale=out_scale, out_shift=out_shift)
+        t_fold = self.fold_plan(mu.shape[-1], y_max) if y_lengths is not None else None
+        if t_fold is not None and (t_out is None or t_out <= t_fold):
+            kw.update(y_lengths=y_lengths, y_max=y_max, t_fold=t_fold)
         if t_len is None:
-            return hip.cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
-                                 out_scale=out_scale, out_shift=out_shift)
+            return hip.cfm_solve(z, mu, mask, t_span, self.solver, **kw)
         hip.set_frame_limits(torch.tensor(list(t_len), dtype=torch.int32, device=mu.device))
         try:
-            return hip.cfm_solve(z, mu, mask, t_span, self.solver, add_mu=self.use_mu_prior, t_out=t_out,
-                                 out_scale=out_scale, out_shift=out_shift)
+            return hip.cfm_solve(z, mu, mask, t_span, self.solver, **kw)
         finally:
             hip.set_frame_limits(None)
 

@@ -85,10 +85,14 @@ class Vocos(ParamTree):
             raise RuntimeError("matcha-tts-24k_amd: mel is not on a HIP device; there is no CPU path")
         mel = mel.detach().to(torch.float32).contiguous()
         B, _, T = mel.shape
-        ws = self._ws.get((B, T))
-        if ws is None:
-            ws = torch.empty(lib.mtts_vocos_workspace_bytes(self._ctx, B, T), dtype=torch.uint8, device=mel.device)
-            self._ws[(B, T)] = ws
+        need = lib.mtts_vocos_workspace_bytes(self._ctx, B, T)
+        key = _hip.stream_ptr()                     # one grow-only scratch buffer per stream (see HipModel._workspace)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = None
+            self._ws.pop(key, None)
+            ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
+            self._ws[key] = ws
         audio = torch.empty(B, self.cfg["hop"] * (T - 1), dtype=torch.float32, device=mel.device)
         _hip.check(lib.mtts_vocos_decode(self._ctx, _hip.ptr(mel), B, T, _hip.ptr(audio), ws.data_ptr(), ws.numel(), _hip.stream_ptr()))
         return audio

@@ -80,6 +80,34 @@ def maxabs(a, b):
     return float((a - b).abs().max())
 
 
+def trim_cases(synthetic):
+    """name -> (1-D waveform, threshold dB): regenerated from seeds by tests/test_trim.py, only the reference's output
+    lengths are stored."""
+    win = 240
+    def noise(n, seed, amp=0.1):
+        return torch.from_numpy(synthetic.portable_normal(seed, 5, n)) * amp
+    cases = {}
+    a = noise(10 * win + 37, 1); a[6 * win:] = 0.0
+    cases["silent_tail_with_remainder"] = (a, -60.0)
+    a = noise(10 * win + 37, 2); a[6 * win: 10 * win] = 0.0            # loud remainder is never examined
+    cases["loud_remainder_ignored"] = (a, -60.0)
+    cases["all_silent"] = (torch.zeros(5 * win + 100), -60.0)
+    cases["all_loud"] = (noise(7 * win, 3), -60.0)
+    cases["shorter_than_a_window"] = (torch.zeros(win - 1), -60.0)
+    cases["exactly_one_silent_window"] = (torch.zeros(win), -60.0)
+    a = noise(8 * win, 4); a[5 * win:] = 1e-3                            # rms == threshold exactly: `<` keeps the window
+    cases["threshold_equality"] = (a, -60.0)
+    a = noise(8 * win, 5); a[5 * win:] = 0.9e-3
+    cases["just_below_threshold"] = (a, -60.0)
+    a = noise(9 * win + 5, 6); a[4 * win:] = 0.0; a[7 * win + 3] = 0.5   # a click inside the silent tail stops the run
+    cases["click_in_tail"] = (a, -60.0)
+    a = noise(9 * win, 7); a[3 * win:] = 0.004
+    cases["other_threshold_db"] = (a, -40.0)
+    a = noise(6 * win, 8); a[2 * win:] = 0.0; a[4 * win + 1] = float("nan")
+    cases["nan_window_stops_the_run"] = (a, -60.0)
+    return cases
+
+
 @torch.inference_mode()
 def main():
     ref_inf = import_reference()
@@ -249,6 +277,10 @@ def main():
     m1 = dp_fixture("dp_tiny", hparams.tiny(n_spks=2), [12, 9, 4], seed_w=7, seed_x=1234, sc=1.03, ls=0.9)
     m2 = dp_fixture("dp_prod", hparams.prod_v20(n_spks=3), [128, 96], seed_w=7, seed_x=1234, sc=1.0, ls=1.0)
     assert min(m1, m2) > 2e-3, ("pick other seeds: a duration sits on a rounding boundary", m1, m2)
+
+    # ------------------------------------------------------------------ trailing-silence trim (inference.py:268-287)
+    np.savez(HERE / "trim.npz", **{f"len_{k}": np.array(len(ref_inf.trim_trailing_silence(a, db)))
+                                   for k, (a, db) in trim_cases(synthetic).items()})
 
     np.savez(HERE / "randn42.npz", head=synthetic.cpu_noise((1, 100, 640)).flatten()[:16].numpy(),
              tail=synthetic.cpu_noise((1, 100, 640)).flatten()[-16:].numpy())

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mtts.h but not exported"
-    assert lib.mtts_abi_version() == 1
+    assert lib.mtts_abi_version() == 2
 
 
 def test_context_rejects_bad_configs_and_missing_tensors(lib, hparams):

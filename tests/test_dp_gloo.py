@@ -64,7 +64,7 @@ def _worker(rank, world, port, n_utts, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_utts", [4, 5])
+@pytest.mark.parametrize("n_utts", [4, 5, 1])   # 1: rank 1 has an empty shard and must still join the collectives
 def test_dp_equals_single_process(tmp_path, oracle, hparams, synthetic, n_utts):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n_utts, str(tmp_path)), nprocs=2, join=True)

@@ -357,6 +357,88 @@ def test_config2_batch32_properties(prod, synthetic, dev):
         assert maxabs(out[:1], _t(g["mel_euler10"])) < MEL_TOL
 
 
+# ------------------------------------------------------------------------------------------------ folded padding
+def _synth_both(model, x, x_len, steps, dev, align, **kw):
+    """The same call on folded padding (rows per utterance from `align`) and on all T_pad reference frames."""
+    dec = model.decoder
+    keep = (dec.fold_padding, dec.fold_align)
+    try:
+        dec.fold_padding, dec.fold_align = True, align
+        folded = model.synthesise(x.to(dev), x_len.to(dev), steps, **kw)
+        dec.fold_padding = False
+        full = model.synthesise(x.to(dev), x_len.to(dev), steps, **kw)
+    finally:
+        dec.fold_padding, dec.fold_align = keep
+    return folded, full
+
+
+@pytest.mark.parametrize("align", [1, 3, 8])
+@pytest.mark.parametrize("lengths,solver,steps", [([12, 9], "euler", 2), ([12], "midpoint", 2), ([3, 12, 1], "rk4", 1), ([2, 1], "euler", 2),
+                                                  ([1], "euler", 1), ([11, 12, 12, 5, 7], "midpoint", 3)])
+def test_tiny_folded_padding_equals_full_padding(tiny, synthetic, oracle, dev, lengths, solver, steps, align):
+    """include/mtts.h mtts_cfm_solve_folded on the tiny estimator (fp32-operand kernels, separate GroupNorm passes): valid rows
+    + one row for all padded frames must reproduce the run over every reference frame -- incl. one-frame utterances (no padded
+    frame at the coarse level), ragged batches (per-utterance multiplicities) and row counts that are not tile multiples -- and
+    the oracle."""
+    hp, sd, model = tiny
+    B = len(lengths)
+    x, x_len, spk = synthetic.make_inputs(hp, B, max(lengths), seed=41, lengths=lengths)
+    model.decoder.solver = solver
+    z = lambda t_pad: synthetic.cpu_noise((B, hp.n_feats, t_pad)).to(dev)
+    folded, full = _synth_both(model, x, x_len, steps, dev, align, speaker=spk.to(dev), z=z)
+    assert folded["mel"].shape == full["mel"].shape
+    assert maxabs(folded["mel"], full["mel"]) < 5e-5
+    with torch.inference_mode():
+        ref = oracle.synthesise(sd, hp, x, x_len, steps, speaker=spk, solver=solver)
+    assert maxabs(folded["mel"], ref["mel"]) < MEL_TOL
+
+
+def test_folding_is_what_synthesise_runs_at_prod_shapes(prod, synthetic, dev):
+    """The default plan at BASELINE config #2's shape: 320 valid of 640 frames -> 384 rows per utterance (161 + 1 rounded to a
+    multiple of 32 at the coarse level, doubled); the golden tests above therefore already exercise the folded estimator.  Here:
+    folded == unfolded at production width (P16 kernels, GroupNorm statistics from the conv epilogues, fused ResNet tail),
+    ragged, with the default and an unaligned row count (statistics fall back to the separate pass)."""
+    hp, sd, model = prod
+    assert model.decoder.fold_padding and model.decoder.fold_plan(640, 320) == 384
+    assert model.decoder.fold_plan(640, 639) is None and model.decoder.fold_plan(2, 1) is None
+    lengths = [128, 100, 77, 128]
+    x, x_len, _ = synthetic.make_inputs(hp, 4, 128, seed=1234, lengths=lengths)
+    z = synthetic.cpu_noise((4, 100, 640)).to(dev)
+    model.decoder.solver = "euler"
+    for align in (32, 5):
+        folded, full = _synth_both(model, x, x_len, 2, dev, align, speaker=0, z=z)
+        assert torch.equal(folded["mel_lengths"], full["mel_lengths"])
+        assert maxabs(folded["mel"], full["mel"]) < 1e-4, align
+
+
+@pytest.mark.parametrize("channels,n_blocks,heads", [((128, 128), 1, 2), ((128, 256), 1, 2)])
+def test_small_p16_decoders_folded_vs_full(channels, n_blocks, heads, hparams, synthetic, dev):
+    """Narrow P16 estimators (16-channel groups: statistics from the separate pass; unequal level widths) folded vs full."""
+    import dataclasses
+    hp = hparams.tiny(n_spks=2)
+    hp = dataclasses.replace(hp, decoder=dataclasses.replace(hp.decoder, channels=channels, attention_head_dim=64,
+                                                             n_blocks=n_blocks, num_mid_blocks=1, num_heads=heads))
+    sd = synthetic.make_state_dict(hp, seed=21)
+    model = make_model(hp, sd, dev)
+    lengths = [14, 9, 3]
+    x, x_len, spk = synthetic.make_inputs(hp, 3, max(lengths), seed=8, lengths=lengths)
+    model.decoder.solver = "midpoint"
+    for align in (1, 16):
+        folded, full = _synth_both(model, x, x_len, 2, dev, align, speaker=spk.to(dev))
+        assert maxabs(folded["mel"], full["mel"]) < 5e-5, align
+
+
+def test_per_request_padding_on_folded_rows(tiny, prod, synthetic, dev):
+    """per_request_padding composes with folding: utterance b's reference length is its own T_pad_b (mtts_set_frame_limits),
+    the multiplicities follow it."""
+    for (hp, sd, model), lengths, align in ((tiny, [12, 9, 5, 1], 1), (prod, [128, 60, 77], 32)):
+        x, x_len, spk = synthetic.make_inputs(hp, len(lengths), max(lengths), seed=99, lengths=lengths)
+        model.decoder.solver = "euler"
+        spk = spk % hp.n_spks
+        folded, full = _synth_both(model, x, x_len, 2, dev, align, speaker=spk.to(dev), per_request_padding=True)
+        assert maxabs(folded["mel"], full["mel"]) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ duration predictor live
 @pytest.mark.parametrize("tag,which", [("dp_tiny", "tiny"), ("dp_prod", "prod")])
 def test_duration_predictor_live_vs_golden(tag, which, hparams, synthetic, dev):
