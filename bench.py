@@ -276,7 +276,12 @@ def main():
             "attention": {"tflops": round(fl_a / (ms_a * 1e-3) / 1e12, 2), "ms_per_step": round(ms_a / args.steps, 3),
                           "launches_per_step": n_a // args.steps},
             "elementwise_ms_per_step": round(ms_e / args.steps, 3), "elementwise_launches_per_step": n_e // args.steps,
-            "whole_path_tflops": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE * {'euler': 1, 'midpoint': 2, 'rk4': 4}[SOLVER]) * args.steps / el / 1e12, 2),
+            # two FLOP counts: what the kernels executed (folded padding: valid rows + one row for all padded frames, rounded up to
+            # whole tiles) -- `achieved` / `frac` above come from this one -- and SURVEY 8d's strict-padding count of the reference
+            "executed_tflop_per_step": round((fl_g + fl_a) / args.steps / 1e12, 3),
+            "strict_padding_tflop_per_step": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE * {'euler': 1, 'midpoint': 2, 'rk4': 4}[SOLVER]) / 1e12, 3),
+            "rows_per_utterance": {"reference_T_pad": t_pad, "held": model.decoder.fold_plan(t_pad, valid_per_utt) or t_pad},
+            "whole_path_tflops_strict_padding_equivalent": round(algorithmic_flops(hp, BATCH, t_pad, N_TOKENS, N_STEPS_ODE * {'euler': 1, 'midpoint': 2, 'rk4': 4}[SOLVER]) * args.steps / el / 1e12, 2),
             "ms_per_step_with_events": round(p_el / args.steps * 1e3, 2),
         }
 
@@ -293,7 +298,8 @@ def main():
             "config": {"workload": ("" if default_cfg else f"NON-DEFAULT batch={BATCH} {SOLVER}/{N_STEPS_ODE}{' + Vocos head' if args.with_vocoder else ''} variant of ") +
                                    "configs[1]: batch=32 random phoneme seqs len=128, n_spks=1, euler n_timesteps=10, fp32, "
                                    "prod v20 architecture, random-init weights, T_pad=640 / 320 valid frames per utterance "
-                                   "(reference 2x padding), noise from the device seed-42 generator",
+                                   "(reference 2x padding kept in the results; the estimator folds the identical padded frames, DESIGN.md section 4), "
+                                   "noise from the device seed-42 generator",
                        "per_gpu_batch": BATCH, "global_batch": BATCH * world, "n_tokens": N_TOKENS, "parallelism": f"dp{world}" + ("" if backend == "nccl" or world == 1 else f" REHEARSAL over {backend} on {n_dev} device(s)"),
                        "n_feats": hp.n_feats, "note": "the reference fork uses 100 mel bins (Vocos-24k), not 80"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -98,6 +98,12 @@ int mtts_speaker_embedding(mtts_ctx* ctx, int table, const int64_t* d_ids, int B
 int mtts_durations(const float* d_logw, const float* d_x_mask, float scale_correction, float length_scale, int B, int Tx,
                    float* d_durations, int32_t* d_cum, int64_t* d_y_fine_lengths, void* stream);
 
+/* The same with one (scale_correction, length_scale) pair per utterance, device float [B] each: a serving batch mixes voices
+ * (reference inference.py:16-32 VOICES[..]["scale_correction"], server.py:111-115) and client speeds. */
+int mtts_durations_per_utterance(const float* d_logw, const float* d_x_mask, const float* d_scale_correction,
+                                 const float* d_length_scale, int B, int Tx, float* d_durations, int32_t* d_cum,
+                                 int64_t* d_y_fine_lengths, void* stream);
+
 /* generate_path + matmul + downsample + sequence_mask -- reference inference.py:146-167,
  * utils/model.py:7-9,24-40,57-68.  T_pad = fix_len_compatibility(max fine length) (host decides it).
  * Outputs: d_mu_y [B,n_feats,T_pad], d_y_mask [B,1,T_pad], d_y_lengths [B] int64. */
@@ -239,6 +245,8 @@ int mtts_prof_reset(mtts_ctx* ctx);
 /* Synchronises the recorded events; returns launches, summed milliseconds, algorithmic FLOPs and compulsory HBM
  * bytes (every operand and result element once) of a class. */
 int mtts_prof_read(mtts_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops, double* bytes);
+/* The same records one by one, in launch order: h_out[4 i ..] = (class, ms, flops, bytes); returns the count (<= max_records). */
+int64_t mtts_prof_records(mtts_ctx* ctx, double* h_out, int64_t max_records);
 
 #ifdef __cplusplus
 }

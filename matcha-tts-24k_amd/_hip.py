@@ -123,6 +123,7 @@ def load() -> C.CDLL:
         "mtts_text_encoder_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
         "mtts_speaker_embedding": (i32, [vp, i32, vp, i32, vp, vp]),
         "mtts_durations": (i32, [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp]),
+        "mtts_durations_per_utterance": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
         "mtts_align_pool": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "mtts_set_frame_limits": (i32, [vp, vp]),
         "mtts_decoder_workspace_bytes": (i64, [vp, i32, i32]),
@@ -152,6 +153,7 @@ def load() -> C.CDLL:
         "mtts_gemm_terms": (i32, [vp]),
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
+        "mtts_prof_records": (i64, [vp, C.POINTER(C.c_double), i64]),
         "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -318,12 +320,24 @@ class HipModel:
         check(self.lib.mtts_speaker_embedding(self.ctx, table, ptr(ids), ids.numel(), ptr(out), stream_ptr()))
         return out
 
-    def durations(self, logw, x_mask, scale_correction: float, length_scale: float):
+    def durations(self, logw, x_mask, scale_correction, length_scale):
+        """``scale_correction`` / ``length_scale``: floats, or per-utterance sequences / tensors of B values."""
         logw, x_mask = self._f32(logw), self._f32(x_mask)
         B, _, Tx = logw.shape
         dur = torch.empty(B, Tx, dtype=torch.float32, device=logw.device)
         cum = torch.empty(B, Tx, dtype=torch.int32, device=logw.device)
         yfl = torch.empty(B, dtype=torch.int64, device=logw.device)
+        if not (isinstance(scale_correction, (int, float)) and isinstance(length_scale, (int, float))):
+            def per_utt(v):
+                t = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+                t = t.expand(B) if t.numel() == 1 else t
+                if t.numel() != B:
+                    raise ValueError("per-utterance scale factors need one value per utterance")
+                return t.to(logw.device).contiguous()
+            sc, ls = per_utt(scale_correction), per_utt(length_scale)
+            check(self.lib.mtts_durations_per_utterance(ptr(logw), ptr(x_mask), ptr(sc), ptr(ls), B, Tx, ptr(dur), ptr(cum),
+                                                        ptr(yfl), stream_ptr()))
+            return dur, cum, yfl
         check(self.lib.mtts_durations(ptr(logw), ptr(x_mask), float(scale_correction), float(length_scale), B, Tx, ptr(dur),
                                       ptr(cum), ptr(yfl), stream_ptr()))
         return dur, cum, yfl
@@ -402,6 +416,15 @@ class HipModel:
         n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
         check(self.lib.mtts_prof_read(self.ctx, klass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return n.value, ms.value, fl.value, by.value
+
+
+    def prof_records(self, max_records: int = 1 << 16):
+        """[(class, ms, flops, bytes)] per launch of the event pass, in launch order."""
+        buf = (C.c_double * (4 * max_records))()
+        n = self.lib.mtts_prof_records(self.ctx, buf, max_records)
+        if n < 0:
+            check(-1)
+        return [(int(buf[4 * i]), buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(n)]
 
 
 # ---------------------------------------------------------------------- single kernels (used by the parity tests)

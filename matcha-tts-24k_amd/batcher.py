@@ -6,7 +6,8 @@ ONE ragged batch -- without changing any request's audio.  ``per_request_padding
 of the batch equals the batch-of-one result (to rounding: tile shapes, hence summation order, depend on the grid).
 
 ``FrameBudgetBatcher`` is the queue + grouping policy:
-  * requests are grouped by what must be uniform inside one call (solver, n_timesteps, scale_correction, length_scale);
+  * requests are grouped by what must be uniform inside one call (solver, n_timesteps); voices, their duration scale
+    corrections and client speeds are per-utterance inputs (mtts_durations_per_utterance);
   * a batch takes the oldest waiting request and then the waiting requests of the same group that are closest to it in token
     count (padding wastes MFMA work: the estimator's cost is ~linear in padded frames), up to ``max_batch`` utterances and
     ``max_tokens`` padded tokens (B * longest), the frame budget idea of the reference's training sampler
@@ -39,7 +40,7 @@ class Request:
 
     @property
     def group(self) -> Tuple[Any, ...]:
-        return (self.solver, int(self.n_timesteps), float(self.scale_correction), float(self.length_scale))
+        return (self.solver, int(self.n_timesteps))
 
 
 def plan_batch(waiting: List[Request], max_batch: int, max_tokens: int) -> List[int]:
@@ -66,8 +67,12 @@ class FrameBudgetBatcher:
     """``submit()`` from any thread; results arrive on the request's future as ``{"mel": [n_feats, T_b], "mel_length": T_b}``."""
 
     def __init__(self, model, max_batch: int = 32, max_tokens: int = 8192, max_wait_ms: float = 2.0,
-                 run_batch: Optional[Callable[[List[Request]], List[Dict[str, Any]]]] = None):
+                 run_batch: Optional[Callable[[List[Request]], List[Dict[str, Any]]]] = None, vocoder=None):
+        """``vocoder``: a ``load_vocoder("vocos")`` object; results then also carry ``"audio"`` = the reference handler's
+        ``trim_trailing_silence(to_waveform(mel, vocoder))`` (reference inference.py:246, server.py:116), computed per request on
+        its exact-length mel (the vocoder's k7 convolutions would otherwise see a neighbour-dependent padded tail)."""
         self.model = model
+        self.vocoder = vocoder
         self.max_batch = int(max_batch)
         self.max_tokens = int(max_tokens)
         self.max_wait = float(max_wait_ms) / 1e3
@@ -145,7 +150,12 @@ class FrameBudgetBatcher:
         head = batch[0]
         self.model.decoder.solver = head.solver
         out = self.model.synthesise(x.to(dev), x_len.to(dev), head.n_timesteps, speaker=spk.to(dev),
-                                    scale_correction=head.scale_correction, length_scale=head.length_scale,
-                                    per_request_padding=True)
+                                    scale_correction=[r.scale_correction for r in batch],
+                                    length_scale=[r.length_scale for r in batch], per_request_padding=True)
         lens = out["mel_lengths"].tolist()
-        return [{"mel": out["mel"][b, :, :int(lens[b])], "mel_length": int(lens[b])} for b in range(B)]
+        res = [{"mel": out["mel"][b, :, :int(lens[b])], "mel_length": int(lens[b])} for b in range(B)]
+        if self.vocoder is not None:
+            from .inference import _waveform_on_device, trim_trailing_silence
+            for r in res:
+                r["audio"] = trim_trailing_silence(_waveform_on_device(r["mel"][None], self.vocoder).squeeze()).cpu()
+        return res

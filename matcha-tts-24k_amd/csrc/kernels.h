@@ -221,7 +221,7 @@ hipError_t launch_seq_mask(const int64_t* lengths, int B, int T, float* mask, hi
 hipError_t launch_bcast_rows(const float* src, int B, int T, int C, const float* mask, float* dst, int ld, int col_off, hipStream_t s);
 hipError_t launch_rope(float* qkv, int B, int T, int H, int D, int d_rope, const float* cos_t, const float* sin_t, hipStream_t s);
 hipError_t launch_durations(const float* logw, const float* mask, float scale_correction, float length_scale, int B, int Tx, float* dur,
-                            int32_t* cum, int64_t* yfl, hipStream_t s);
+                            int32_t* cum, int64_t* yfl, hipStream_t s, const float* sc_b = nullptr, const float* ls_b = nullptr);
 // level mask of the U-Net: dst[b, t] = src[b, t * stride], t < T_dst (reference decoder.py:390 mask[:, :, ::2])
 hipError_t launch_mask_down(const float* src, int B, int T_src, int stride, float* dst, int T_dst, hipStream_t s);
 // Per-level frame tables of one estimator call (norm_glue.hip).  Level l has T[l] rows per utterance.

@@ -1269,6 +1269,14 @@ int mtts_durations(const float* d_logw, const float* d_x_mask, float scale_corre
     return 0;
 }
 
+int mtts_durations_per_utterance(const float* d_logw, const float* d_x_mask, const float* d_scale_correction, const float* d_length_scale,
+                                 int B, int Tx, float* d_durations, int32_t* d_cum, int64_t* d_y_fine_lengths, void* stream) {
+    if (!d_scale_correction || !d_length_scale) { set_error("mtts_durations_per_utterance: null factor array"); return -1; }
+    HIP_OK(launch_durations(d_logw, d_x_mask, 1.0f, 1.0f, B, Tx, d_durations, d_cum, d_y_fine_lengths, static_cast<hipStream_t>(stream),
+                            d_scale_correction, d_length_scale));
+    return 0;
+}
+
 int mtts_align_pool(const float* d_mu_x, const int32_t* d_cum, const int64_t* d_y_fine_lengths, int B, int n_feats, int Tx, int T_pad,
                     float* d_mu_y, float* d_y_mask, int64_t* d_y_lengths, void* stream) {
     HIP_OK(launch_align_pool(d_mu_x, d_cum, d_y_fine_lengths, B, n_feats, Tx, T_pad, d_mu_y, d_y_mask, d_y_lengths,
@@ -1452,6 +1460,20 @@ int mtts_prof_read(mtts_ctx* c, int klass, int64_t* launches, double* ms, double
     return 0;
 }
 
+// Per-launch records of the event pass, in launch order: out[i] = (class, ms, flops, bytes); returns the number written.
+int64_t mtts_prof_records(mtts_ctx* c, double* out, int64_t max_records) {
+    if (!c || !out) { set_error("mtts_prof_records: bad argument"); return -1; }
+    if (!c->prof.empty()) HIP_OK(hipEventSynchronize(c->prof.back().e1));
+    int64_t n = 0;
+    for (const ProfRec& r : c->prof) {
+        if (n >= max_records) break;
+        float el = 0.f;
+        HIP_OK(hipEventElapsedTime(&el, r.e0, r.e1));
+        out[4 * n] = r.klass; out[4 * n + 1] = el; out[4 * n + 2] = r.flops; out[4 * n + 3] = r.bytes;
+        ++n;
+    }
+    return n;
+}
 
 // ================================================================================================ Vocos head
 static int vocos_pack(mtts_vocos* v) {

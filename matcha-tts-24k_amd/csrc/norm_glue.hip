@@ -632,10 +632,13 @@ hipError_t launch_rope(float* qkv, int B, int T, int H, int D, int d_rope, const
 // Durations (reference inference.py:127-146): d = round(((exp(logw) - 2) * mask) * sc * ls).clamp(min=1) * mask,
 // inclusive cumsum as int32, fine length = max(sum, 1).  One workgroup per utterance, serial-chunk + block scan.
 __global__ __launch_bounds__(256) void durations_kernel(const float* __restrict__ logw, const float* __restrict__ mask, float sc, float ls,
+                                                        const float* __restrict__ sc_b, const float* __restrict__ ls_b,
                                                         int Tx, float* __restrict__ dur, int32_t* __restrict__ cum,
                                                         int64_t* __restrict__ yfl) {
     __shared__ int part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (sc_b) sc = sc_b[b];          // per-utterance factors (a batch of requests with different voices / speeds)
+    if (ls_b) ls = ls_b[b];
     const int per = (Tx + 255) / 256;
     const int i0 = tid * per, i1 = min(Tx, i0 + per);
     int s = 0;
@@ -664,9 +667,9 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* __restrict_
     if (tid == 255) yfl[b] = max(part[255], 1);
 }
 hipError_t launch_durations(const float* logw, const float* mask, float sc, float ls, int B, int Tx, float* dur, int32_t* cum,
-                            int64_t* yfl, hipStream_t s) {
+                            int64_t* yfl, hipStream_t s, const float* sc_b, const float* ls_b) {
     if (!logw || !mask || !dur || !cum || !yfl || B <= 0 || Tx <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s, logw, mask, sc, ls, Tx, dur, cum, yfl);
+    hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s, logw, mask, sc, ls, sc_b, ls_b, Tx, dur, cum, yfl);
     return hipGetLastError();
 }
 

@@ -104,7 +104,7 @@ class CFM(nn.Module):
         self.sigma_min = hp.sigma_min
         self.use_mu_prior = hp.use_mu_prior
         self.fold_padding = os.environ.get("MTTS_FOLD", "1") != "0"
-        self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "32"))
+        self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "8"))
         object.__setattr__(self, "_rt", rt)
         self.estimator = Estimator()
         self.estimator._bind(rt)
@@ -130,8 +130,10 @@ class CFM(nn.Module):
 
     def fold_plan(self, T: int, y_max: Optional[int]) -> Optional[int]:
         """Rows per utterance for the folded estimator (include/mtts.h mtts_cfm_solve_folded), or None to run all T frames.
-        ``fold_padding`` (attribute; env MTTS_FOLD=0 turns the default off) and ``fold_align`` (MTTS_FOLD_ALIGN, default 32:
-        whole wave tiles per utterance at every level) are plain attributes like ``solver``."""
+        ``fold_padding`` (attribute; env MTTS_FOLD=0 turns the default off) and ``fold_align`` (MTTS_FOLD_ALIGN, default 8 rows at
+        the coarsest level: measured best at B = 32 -- 336 / 168 rows for 320 valid frames fill the chip's 256 CUs with whole
+        rounds of tiles; 32 keeps whole wave tiles per utterance for the GroupNorm statistics of the conv epilogues but runs
+        384 / 192 rows) are plain attributes like ``solver``."""
         if not self.fold_padding or y_max is None:
             return None
         t_fold = self._rt.ready().fold_rows(y_max, self.fold_align)

@@ -394,18 +394,18 @@ def test_tiny_folded_padding_equals_full_padding(tiny, synthetic, oracle, dev, l
 
 
 def test_folding_is_what_synthesise_runs_at_prod_shapes(prod, synthetic, dev):
-    """The default plan at BASELINE config #2's shape: 320 valid of 640 frames -> 384 rows per utterance (161 + 1 rounded to a
-    multiple of 32 at the coarse level, doubled); the golden tests above therefore already exercise the folded estimator.  Here:
-    folded == unfolded at production width (P16 kernels, GroupNorm statistics from the conv epilogues, fused ResNet tail),
-    ragged, with the default and an unaligned row count (statistics fall back to the separate pass)."""
+    """The default plan at BASELINE config #2's shape: 320 valid of 640 frames -> 336 rows per utterance (160 + 1 rounded to a
+    multiple of 8 at the coarse level, doubled); the golden tests above therefore already exercise the folded estimator.  Here:
+    folded == unfolded at production width (P16 kernels), ragged, with whole wave tiles per utterance (align 32: GroupNorm
+    statistics from the conv epilogues, fused ResNet tail) and without (statistics from the separate pass)."""
     hp, sd, model = prod
-    assert model.decoder.fold_padding and model.decoder.fold_plan(640, 320) == 384
+    assert model.decoder.fold_padding and model.decoder.fold_plan(640, 320) == 336
     assert model.decoder.fold_plan(640, 639) is None and model.decoder.fold_plan(2, 1) is None
     lengths = [128, 100, 77, 128]
     x, x_len, _ = synthetic.make_inputs(hp, 4, 128, seed=1234, lengths=lengths)
     z = synthetic.cpu_noise((4, 100, 640)).to(dev)
     model.decoder.solver = "euler"
-    for align in (32, 5):
+    for align in (32, 8, 5):
         folded, full = _synth_both(model, x, x_len, 2, dev, align, speaker=0, z=z)
         assert torch.equal(folded["mel_lengths"], full["mel_lengths"])
         assert maxabs(folded["mel"], full["mel"]) < 1e-4, align

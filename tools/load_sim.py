@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""BASELINE config #5: the reference's load test (reference psr/load_test.py:28-62,87-120) as an in-process closed loop.
+
+The reference drives its HTTP server with locust users that POST one of 33 texts, wait for the audio, then sleep for the
+audio's duration (a listener) before the next request.  Here the same closed loop runs in one process against
+``FrameBudgetBatcher`` (dynamic batching in front of ``MatchaTTSInfer.synthesise``) with the reference handler's work per
+request (reference server.py:93-127): synthesise (midpoint, 4 steps = the server defaults) -> Vocos head -> peak normalise ->
+trailing-silence trim -> waveform on the host.  The phonemizer and the MP3/OGG encoders are CPU stages outside the path
+(SURVEY.md section 8): a request is a random id sequence of round(2.3 * characters) tokens (3 ids per
+voiced phoneme; the phonemizer is not runnable offline), characters = the lengths of the reference's 33 TEXT_SAMPLES.
+
+    python tools/load_sim.py [--users 1,8,32,128] [--seconds 20] [--no-vocoder] [--max-batch 32]
+prints one JSON line per user count: requests, p50 / p95 latency (s), p50 / p95 latency per audio-second (= RTF seen by the
+client), audio-seconds per second served, mean batch size.
+"""
+import argparse
+import importlib
+import json
+import random
+import sys
+import threading
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+PKG = "matcha-tts-24k_amd"
+
+# (language, characters) of the reference's TEXT_SAMPLES (psr/load_test.py:28-62), in file order
+TEXT_SAMPLE_CHARS = [("en-us", 430), ("en-us", 236), ("en-us", 162), ("en-us", 434), ("en-us", 142), ("en-us", 91), ("en-us", 428),
+                     ("en-us", 26), ("en-us", 152), ("en-us", 330), ("en-us", 131), ("ro", 356), ("fr-fr", 388), ("en-us", 61),
+                     ("en-us", 58), ("en-us", 57), ("en-us", 64), ("en-us", 78), ("en-us", 192), ("en-us", 184), ("en-gb", 75),
+                     ("en-gb", 69), ("en-gb", 159), ("ro", 78), ("ro", 52), ("ro", 183), ("ro", 84), ("ro", 77), ("fr-fr", 60),
+                     ("fr-fr", 63), ("fr-fr", 179), ("fr-fr", 86), ("fr-fr", 84)]
+TOKENS_PER_CHAR = 2.3
+MAX_TOKENS = 3000
+
+
+def percentile(v, q):
+    if not v:
+        return None
+    s = sorted(v)
+    return s[min(len(s) - 1, int(round(q * (len(s) - 1))))]
+
+
+def run_level(batcher, inference, hp, users, seconds, seed, time_scale=1.0):
+    stop_at = time.monotonic() + seconds
+    lat, lat_per_s, audio_s, lock = [], [], [], threading.Lock()
+    voices_of = {}
+    for v in inference.VOICES:
+        voices_of.setdefault(v["lang"], []).append(v)
+
+    def user(uid):
+        rng = random.Random(seed * 1000 + uid)
+        time.sleep(rng.random() * 0.2)                       # locust spawns users over a ramp, not in one instant
+        while time.monotonic() < stop_at:
+            lang, chars = rng.choice(TEXT_SAMPLE_CHARS)
+            voice = rng.choice(voices_of.get(lang) or inference.VOICES)
+            n_tok = max(1, min(MAX_TOKENS, round(chars * TOKENS_PER_CHAR)))
+            ids = [rng.randrange(hp.n_vocab) for _ in range(n_tok)]
+            t0 = time.monotonic()
+            res = batcher.submit(ids, speaker=int(voice["id"]) % hp.n_spks, solver=inference.DEFAULT_ODE_SOLVER,
+                                 n_timesteps=inference.DEFAULT_NUM_STEPS, scale_correction=voice["scale_correction"],
+                                 length_scale=1.0).result()
+            dt = time.monotonic() - t0
+            dur = (len(res["audio"]) if "audio" in res else res["mel_length"] * inference.STD_RES_HOP_LENGTH) / inference.SAMPLE_RATE
+            with lock:
+                lat.append(dt)
+                audio_s.append(dur)
+                lat_per_s.append(dt / max(dur, 1e-3))
+            time.sleep(dur * time_scale)                     # the listener (reference load_test.py:120 gevent.sleep(duration))
+
+    b0 = batcher.batches_run
+    t0 = time.monotonic()
+    threads = [threading.Thread(target=user, args=(u,), daemon=True) for u in range(users)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.monotonic() - t0
+    nb = max(batcher.batches_run - b0, 1)
+    return {"users": users, "seconds": round(el, 1), "requests": len(lat), "mean_batch": round(len(lat) / nb, 2),
+            "p50_latency_s": percentile(lat, 0.5), "p95_latency_s": percentile(lat, 0.95),
+            "p50_latency_per_audio_s": percentile(lat_per_s, 0.5), "p95_latency_per_audio_s": percentile(lat_per_s, 0.95),
+            "audio_s_per_s": round(sum(audio_s) / el, 1), "mean_audio_s": round(sum(audio_s) / max(len(audio_s), 1), 2)}
+
+
+def build(dev, with_vocoder=True, n_spks=15, max_batch=32, max_tokens=16384, max_wait_ms=2.0):
+    hparams = importlib.import_module(PKG + ".hparams")
+    synthetic = importlib.import_module(PKG + ".synthetic")
+    inference = importlib.import_module(PKG + ".inference")
+    batcher_mod = importlib.import_module(PKG + ".batcher")
+    hp = hparams.prod_v20(n_spks=n_spks)                     # 15 voices (reference inference.py:16-32)
+    model = inference.MatchaTTSInfer(**hp.as_reference_kwargs())
+    model.load_state_dict(synthetic.make_state_dict(hp, seed=7), strict=True)
+    model = model.to(dev).eval()
+    vocoder = inference.load_vocoder("vocos", state_dict=synthetic.make_vocos_state_dict(seed=11)) if with_vocoder else None
+    b = batcher_mod.FrameBudgetBatcher(model, max_batch=max_batch, max_tokens=max_tokens, max_wait_ms=max_wait_ms, vocoder=vocoder)
+    return hp, inference, model, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", default="1,8,32,128")
+    ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--no-vocoder", action="store_true")
+    ap.add_argument("--max-batch", type=int, default=32)
+    ap.add_argument("--max-wait-ms", type=float, default=2.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    hp, inference, model, batcher = build(dev, not args.no_vocoder, max_batch=args.max_batch, max_wait_ms=args.max_wait_ms)
+    try:
+        # warm-up: first-use costs (workspace growth, lazily configured kernels) are not request latency
+        for n in (60, 400, 1000):
+            batcher.submit([1] * n, solver=inference.DEFAULT_ODE_SOLVER, n_timesteps=inference.DEFAULT_NUM_STEPS).result()
+        for u in [int(v) for v in args.users.split(",")]:
+            r = run_level(batcher, inference, hp, u, args.seconds, args.seed)
+            r.update(config="configs[4]: closed-loop users (reference psr/load_test.py), 33 TEXT_SAMPLES lengths x 2.3 tokens/char, "
+                            f"midpoint/4, dynamic batching max_batch={args.max_batch}, per-request padding, "
+                            + ("Vocos head + trim on device" if not args.no_vocoder else "mel only"),
+                     data="synthetic ids, random-init weights", n_gpus=1)
+            print(json.dumps(r), flush=True)
+    finally:
+        batcher.close()
+
+
+if __name__ == "__main__":
+    main()
