@@ -232,6 +232,20 @@ int64_t mtts_vocos_workspace_bytes(mtts_vocos* v, int B, int T);
 int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_audio, void* d_ws, int64_t ws_bytes,
                       void* stream);
 
+/* ---------------------------------------------------------------- arithmetic and its range guard */
+
+/* Range guard of the default arithmetic.  The fp16 two-term split represents an operand x as h + l / 2^11 with h = fp16(x):
+ * beyond +-65504 h saturates and the product is wrong.  Every kernel that splits an operand (the P16 image writers: GEMM
+ * epilogues, attention, GroupNorm-apply, the state conversion; the fp32-operand GEMM while staging) ORs 1 into the FIRST
+ * 32-bit WORD OF THE WORKSPACE of the call it belongs to (mtts_text_encoder_forward / mtts_decoder_forward / mtts_cfm_solve*
+ * clear it on entry): read it back after the call; non-zero = rerun on a context whose arithmetic has the fp32 range
+ * (mtts_set_arithmetic(ctx, 6): three bf16 terms).  The Python mirror does this in synthesise().
+ * mtts_set_arithmetic: products per fp32 multiply-accumulate as for mtts_gemm_f32's `terms` (0, 2, 3, 6; 1 = the opt-in fp16
+ * mode), overriding MTTS_GEMM_TERMS; call before mtts_weights_bytes / mtts_upload_weights (it invalidates the packed image).
+ * mtts_weights_saturate: 1 if a WEIGHT exceeds the fp16 range in the fp16-split mode (decided while packing). */
+int mtts_set_arithmetic(mtts_ctx* ctx, int terms);
+int mtts_weights_saturate(mtts_ctx* ctx);
+
 /* ---------------------------------------------------------------- measurement */
 
 /* GEMM arithmetic of a context (NULL: the library default): 0 native fp32 MFMA, 2 fp16 two-term split (default),

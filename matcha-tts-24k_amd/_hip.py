@@ -151,6 +151,8 @@ def load() -> C.CDLL:
         "mtts_vocos_workspace_bytes": (i64, [vp, i32, i32]),
         "mtts_vocos_decode": (i32, [vp, vp, i32, i32, vp, vp, i64, vp]),
         "mtts_gemm_terms": (i32, [vp]),
+        "mtts_set_arithmetic": (i32, [vp, i32]),
+        "mtts_weights_saturate": (i32, [vp]),
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
         "mtts_prof_records": (i64, [vp, C.POINTER(C.c_double), i64]),
@@ -205,7 +207,8 @@ def time_freqs(dim: int) -> torch.Tensor:
 class HipModel:
     """One mtts_ctx: packed weights on a device + cached workspaces + the path's entry points on torch tensors."""
 
-    def __init__(self, hp: PathHParams):
+    def __init__(self, hp: PathHParams, terms: Optional[int] = None):
+        """``terms``: GEMM arithmetic (mtts_set_arithmetic); None = the library default (fp16 two-term split, MTTS_GEMM_TERMS)."""
         self.lib = load()
         self.hp = hp
         cfg = MttsConfig()
@@ -224,9 +227,12 @@ class HipModel:
         self.ctx = self.lib.mtts_create(C.byref(cfg))
         if not self.ctx:
             raise RuntimeError("mtts_create: " + self.lib.mtts_last_error().decode())
+        if terms is not None:
+            check(self.lib.mtts_set_arithmetic(self.ctx, int(terms)))
         self.weights: Optional[torch.Tensor] = None
         self.device: Optional[torch.device] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._last_ws: Dict[str, torch.Tensor] = {}     # workspace of the latest call per kind: its first word = range flag
 
     def __del__(self):
         try:
@@ -269,6 +275,7 @@ class HipModel:
         check(self.lib.mtts_upload_weights(self.ctx, self.weights.data_ptr(), nbytes))
         self.device = device
         self._ws.clear()
+        self._last_ws.clear()
 
     def _workspace(self, kind: str, a: int, b: int) -> torch.Tensor:
         """One GROW-ONLY scratch buffer per (kind, stream): a serving process sees a new (B, T_pad) with almost every request,
@@ -287,7 +294,22 @@ class HipModel:
             self._ws.pop(key, None)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
+        self._last_ws[key] = ws
         return ws
+
+    def range_flags(self) -> torch.Tensor:
+        """Sticky range flags (include/mtts.h "range guard") of this stream's latest encoder and estimator calls as a device
+        int32 tensor [2]; non-zero = an operand left the fp16 range and saturated.  Reading it (``.any().item()``) synchronises."""
+        z = torch.zeros(1, dtype=torch.int32, device=self.device)
+        sp = stream_ptr()
+        parts = [self._last_ws[(k, sp)][:4].view(torch.int32) if (k, sp) in self._last_ws else z for k in ("enc", "dec")]
+        return torch.cat(parts)
+
+    def weights_saturate(self) -> bool:
+        r = self.lib.mtts_weights_saturate(self.ctx)
+        if r < 0:
+            check(-1)
+        return bool(r)
 
     def workspace_bytes_held(self) -> int:
         return sum(int(w.numel()) for w in self._ws.values())

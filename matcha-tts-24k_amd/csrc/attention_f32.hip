@@ -19,6 +19,7 @@
 // probabilities never leave registers, and the per-query rescale is a lane-uniform multiply of the O^T accumulators.
 // Head dims below 64 (encoder: 48) are zero-padded to 64 in the staged tiles.
 #include "kernels.h"
+#include "device_utils.h"
 #include <cstdlib>
 
 namespace mtts {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     // ---- normalise and store: lane holds query qi; register r of d-tile t is d = 32t + (r&3) + 8(r>>2) + 4h
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    bool range_bad = false;
     if (P16) {
         if (q_in) {
             _Float16* op = p.out16 + (rowbase + qi) * (size_t)p.ldo16 + head * (2 * AT_D);
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     f16x4 hh, ll;
+                    range_bad |= out_of_f16_range(o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv, o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = o[t][4 * g4 + e] * inv;
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     *reinterpret_cast<f16x4*>(op + t * 64 + 32 + 8 * g4 + 4 * h) = ll;
                 }
         }
+        raise_range_flag(p.range_flag, range_bad);
     } else if (q_in) {
         float* op = p.out + (rowbase + qi) * (size_t)(p.H * p.D) + head * p.D;
 #pragma unroll

@@ -14,6 +14,15 @@ __device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
     l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
 }
 
+// Range guard of the fp16 split: an operand beyond +-65504 saturates (h clamps), which the caller must learn about.  Producers
+// OR their lanes' findings into a register and raise the sticky flag once per thread (atomics only on the rare bad path).
+__device__ __forceinline__ bool out_of_f16_range(float a, float b, float c, float d) {
+    return fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) > 65504.f;
+}
+__device__ __forceinline__ void raise_range_flag(unsigned int* flag, bool bad) {
+    if (bad && flag) atomicOr(flag, 1u);
+}
+
 // sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 to r in [-pi/4, pi/4] and the minimax sine
 // kernel; in odd quadrants sin(y)^2 = cos(r)^2 = 1 - sin(r)^2, so one polynomial serves both (sin(r)^2 <= 1/2: the
 // subtraction is benign).  ~1 ulp of sinf(y)^2 for |y| < 1e4 (arguments here are O(10)), a quarter of the library sinf.

@@ -71,6 +71,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         gn_mean[1] = gn_n[1] > 0.f ? t1 / gn_n[1] : 0.f;
     }
     const float gn_mu = gn_gi == 0 ? gn_mean[0] : gn_mean[1];
+    bool range_bad = false;
     // Block1D tail: this lane's group statistics (merged in the prologue into gstat = [mean x 4 | rstd x 4]) and affine
     float gnr_mu = 0.f, gnr_rs = 1.f;
     f32x4 gnr_gm = {0.f, 0.f, 0.f, 0.f}, gnr_bt = gnr_gm;
@@ -162,6 +163,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                     if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)L.orow[u] * p.ldc + nc) = o;
                     if (p.out16) {                           // P16 copy: 8 lanes write one whole 128-B line
                         f16x4 h, l;
+                        range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && L.om16[u] != 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = o[e] * L.om16[u];
@@ -211,6 +213,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         else if (actk == 1) run(IntC<1>{}, IntC<0>{});
         else run(IntC<2>{}, IntC<0>{});
     }
+    raise_range_flag(p.range_flag, range_bad);
     if (gn) {
         const float q0 = allreduce64(gn_gi == 0 ? gn_q : 0.f), q1 = allreduce64(gn_gi == 1 ? gn_q : 0.f);
         if (lane == 0 && m0 + wm * (BM / 2) < M) {

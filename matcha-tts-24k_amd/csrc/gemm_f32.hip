@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
         ld_c += GEMM_BK;
         if (ld_c >= p.ktap) { ld_c = 0; ++ld_tap; }
     };
+    bool range_bad = false;      // terms 2: an A element beyond the fp16 range saturates in split_f16 (GemmArgs::range_flag)
     auto stage = [&](int buf) {
         if constexpr (TERMS == 0) {
             float* As = lds + buf * TILE_FLOATS;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
                 __bf16* d = As + (lrow + 32 * i) * SPLIT_RS + lq;
                 if constexpr (TERMS == 2) {
                     f16x4 h, l;
+                    range_bad |= out_of_f16_range(v[0], v[1], v[2], v[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f16(v[e], a, b); h[e] = a; l[e] = b; }
                     *reinterpret_cast<f16x4*>(d) = h;
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256, (BM == 64 && TERMS != 0) ? 3 : 2) void gemm_f3
                     (TERMS == 2) ? acc[i][j][r] + accx[i][j][r] * (1.0f / F16_RES_SCALE) : acc[i][j][r];
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave, no barrier needed
     __builtin_amdgcn_wave_barrier();
+    if constexpr (TERMS == 2) raise_range_flag(p.range_flag, range_bad);
 
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int nc = n0 + wn * 64 + (lane & 15) * 4;          // first of this lane's 4 columns

@@ -454,14 +454,16 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ fp32 <-> P16
 __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C, int C_valid,
-                              _Float16* __restrict__ out, int ld16, float lscale) {
+                              _Float16* __restrict__ out, int ld16, float lscale, unsigned int* range_flag) {
     const int c4n = C >> 2;
     const size_t n = (size_t)M * c4n;
+    bool range_bad = false;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / c4n), c = (int)(i - (size_t)row * c4n) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < C_valid) v = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + c);     // C_valid % 4 == 0
         if (mask) v *= mask[row];
+        range_bad |= out_of_f16_range(v[0], v[1], v[2], v[3]);
         f16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -472,15 +474,16 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
         *reinterpret_cast<f16x4*>(o) = h;
         *reinterpret_cast<f16x4*>(o + 32) = l;
     }
+    raise_range_flag(range_flag, range_bad);
 }
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s) {
+                         hipStream_t s, unsigned int* range_flag) {
     if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || C_valid > C || (C_valid & 3) || ld < C_valid || ld16 < 2 * C || (ld16 & 3))
         return hipErrorInvalidValue;
     const size_t n = (size_t)M * (C >> 2);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale);
+    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale, range_flag);
     return hipGetLastError();
 }
 __global__ void from_p16_kernel(const _Float16* __restrict__ x, int ld16, int M, int C, float inv_lscale, float* __restrict__ out, int ld) {

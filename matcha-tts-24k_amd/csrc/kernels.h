@@ -87,13 +87,16 @@ struct GemmArgs {
     const int* gnr_nextra = nullptr;      // folded padding (GnApplyArgs::nextra / bias_stats): copies of the producing conv's bias
     const float* gnr_bias_stats = nullptr;//   row that belong to the statistics without existing as rows
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
+    // fp16-split arithmetic only: set to 1 (sticky, atomicOr) when an operand this launch splits -- an A element while staging
+    // (gemm_f32.hip, terms 2) or an out16 element (epilogue) -- lies beyond +-65504 and saturates.  Null = no check.
+    unsigned int* range_flag = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
 int gemm_p16_wave_rows(const GemmArgs& a);                          // rows of a wave tile (BM/2) launch_gemm_p16 will use for these shapes
 // fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s);   // channels [C_valid, C) are written as zeros
+                         hipStream_t s, unsigned int* range_flag = nullptr);   // channels [C_valid, C) are written as zeros
 hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
@@ -133,6 +136,7 @@ struct AttnArgs {
                                   // additive key bias itself: 1 for valid frames, ln(n_pad) for the one row that stands for n_pad
                                   // identical padded frames (reference bias +0 each)
     bool fast16 = false;          // P16 I/O only: single fp16 product per MAC (no residual terms)
+    unsigned int* range_flag = nullptr;   // P16 output: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
@@ -195,6 +199,7 @@ struct GnApplyArgs {
     const float* tile_stats = nullptr;// alternative to `partial`: the entries a P16 GEMM's epilogue left (GemmArgs::gn_stats)
     int tile_rows = 0;                // rows per wave tile of that GEMM (gemm_p16_wave_rows); T % tile_rows == 0
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
+    unsigned int* range_flag = nullptr;   // out16: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 

@@ -78,6 +78,8 @@ struct mtts_ctx {
     float* d_image = nullptr;     // caller-owned device buffer
     bool packed = false, uploaded = false;
     int gemm_terms = 6;           // 0: fp32 MFMA, 6 / 3: split-bf16 MFMA, 2: split-fp16 (MTTS_GEMM_TERMS; see gemm_f32.hip)
+    unsigned int* cur_flag = nullptr;   // range flag of the call being enqueued: first word of its workspace (include/mtts.h)
+    bool weights_saturate = false;      // fp16-split mode: a weight beyond +-65504 was met while packing
     const int* d_tlen = nullptr;  // per-utterance frame limits of the next estimator calls (mtts_set_frame_limits), device [B]
     bool fast16 = false;          // MTTS_GEMM_TERMS=1 at mtts_create: the estimator's P16 kernels multiply the fp16 heads only
     bool p16_on = true;           // fp16-split mode: activations as P16 images between kernels (MTTS_P16=0 at mtts_create disables)

@@ -54,12 +54,28 @@ static int prof_end(mtts_ctx* c, hipStream_t s) {
         RET_IF(prof_end(ctx, stream));           \
     } while (0)
 
-static int run_gemm(mtts_ctx* c, const GemmArgs& a, hipStream_t s) {
+static int run_gemm(mtts_ctx* c, const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.range_flag = c->cur_flag;
     LAUNCHB(c, 0, gemm_flops(a), gemm_bytes(a), s, launch_gemm(a, s));
     return 0;
 }
-static int run_attn(mtts_ctx* c, const AttnArgs& a, hipStream_t s) {
+static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    a.range_flag = c->cur_flag;
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
+    return 0;
+}
+static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
+    GnApplyArgs a = a0;
+    a.range_flag = c->cur_flag;
+    RET_IF(run_gn_apply(c, a, s));
+    return 0;
+}
+// The sticky range flag of a call = the first word of its workspace, cleared here (include/mtts.h "range guard").
+static int begin_call(mtts_ctx* c, void* d_ws, hipStream_t s) {
+    c->cur_flag = static_cast<unsigned int*>(d_ws);
+    HIP_OK(hipMemsetAsync(d_ws, 0, 256, s));
     return 0;
 }
 
@@ -139,6 +155,8 @@ struct Packer {
         const size_t n = (size_t)round_up(p.N, GEMM_BN) * p.ntaps * p.ktap;
         p.w16 = alloc((3 * n + 1) / 2);
         if (c->gemm_terms == 2) {
+            for (size_t i = 0; i < n; ++i)
+                if (std::fabs(c->image[p.w + i]) > 65504.f) { c->weights_saturate = true; break; }
             split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
             const int Np = round_up(p.N, GEMM_BN);
             const size_t Kp = (size_t)p.ntaps * p.ktap;
@@ -204,6 +222,7 @@ struct Packer {
 static int pack_all(mtts_ctx* c) {
     const mtts_config& g = c->cfg;
     c->image.clear();
+    c->weights_saturate = false;
     Packer P(c);
     auto S = [](const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; };
     const int taps3[3] = {-1, 0, 1};
@@ -447,6 +466,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     const size_t M0 = (size_t)B * T;
     d.Tl.resize(d.nl);
     d.mask.resize(d.nl); d.bufA.resize(d.nl); d.bufB.resize(d.nl); d.skip.resize(d.nl);
+    (void)ws.bytes(256);                 // header: the call's range flag (begin_call)
     d.nrows.resize(d.nl); d.nextra.resize(d.nl); d.kbias.resize(d.nl);
     for (int l = 0; l < d.nl; ++l) {
         d.Tl[l] = T >> l;
@@ -528,7 +548,7 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
     g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.nrows = d.nr(lvl);
     if (d.folded) { g1.nextra = d.ne(lvl); g1.bias_stats = W(c, r.gn1_bs.off); }
     g1.chbias = tbias; g1.out = d.Hh; g1.B = B; g1.T = T; g1.C = C;
-    LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
+    RET_IF(run_gn_apply(c, g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a0 = d.Hh; b.lda0 = C; b.c0 = C; b.out = d.Y; b.ldc = C;      // Hh is already masked
@@ -547,7 +567,7 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
         g2.stats_out = d.lnp;
         if (p16_blocks(c, C)) { g2.out16 = d.X16; g2.ld16 = 2 * C; }
     }
-    LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
+    RET_IF(run_gn_apply(c, g2, s));
     return 0;
 }
 
@@ -725,7 +745,7 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.nrows = d.nr(0);
     if (d.folded) { ga.nextra = d.ne(0); ga.bias_stats = W(c, D.fgn_bs.off); }
     ga.out = d.Hh; ga.B = B; ga.T = T; ga.C = C0;
-    LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
+    RET_IF(run_gn_apply(c, ga, s));
     GemmArgs p;
     panel_args(c, D.final_proj, p); rows_plain(p, B, T);
     p.a0 = d.Hh; p.lda0 = C0; p.c0 = C0; p.out_mask = d.mask[0];
@@ -764,7 +784,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.nrows = d.nr(lvl);
     if (d.folded) { g1.nextra = d.ne(lvl); g1.bias_stats = W(c, r.gn1_bs.off); }
     g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
-    LAUNCH(c, 2, 0, s, launch_gn_apply(g1, s));
+    RET_IF(run_gn_apply(c, g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
     b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
@@ -795,7 +815,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     if (d.folded) { g2.nextra = d.ne(lvl); g2.bias_stats = W(c, r.gn2_bs.off); }
     g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;
     g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
-    LAUNCH(c, 2, 0, s, launch_gn_apply(g2, s));
+    RET_IF(run_gn_apply(c, g2, s));
     return 0;
 }
 
@@ -806,7 +826,7 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     const float* tb = d.TB + (size_t)ev * D.tb_total;
     size_t ri = 0, ti = 0;
     // masked x | mu | zero padding as a P16 image (reference decoder.py:379: the first ResNet sees x * mask)
-    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, 2 * d.ldx, 2048.0f, s));
+    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, 2 * d.ldx, 2048.0f, s, c->cur_flag));
     const _Float16* cur = d.XM16;
     int cur_c = d.ldx;
     // ---- down path
@@ -887,7 +907,7 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.nrows = d.nr(0);
     if (d.folded) { ga.nextra = d.ne(0); ga.bias_stats = W(c, D.fgn_bs.off); }
     ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
-    LAUNCH(c, 2, 0, s, launch_gn_apply(ga, s));
+    RET_IF(run_gn_apply(c, ga, s));
     GemmArgs p;
     panel_args(c, D.final_proj, p); rows_plain(p, B, T);
     p.a16_0 = d.H16; p.lda16_0 = 2 * C0; p.c0 = C0; p.out_mask = d.mask[0];
@@ -955,6 +975,22 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     return c;
 }
 
+int mtts_set_arithmetic(mtts_ctx* c, int terms) {
+    if (!c) { set_error("null context"); return -1; }
+    if (terms != 0 && terms != 1 && terms != 2 && terms != 3 && terms != 6) { set_error("mtts_set_arithmetic: terms must be 0, 1, 2, 3 or 6"); return -1; }
+    c->fast16 = terms == 1;
+    c->gemm_terms = terms == 1 ? 2 : terms;
+    c->packed = false;
+    c->uploaded = false;
+    return 0;
+}
+
+int mtts_weights_saturate(mtts_ctx* c) {
+    if (!c) { set_error("null context"); return -1; }
+    if (!c->packed && pack_all(c)) return -1;
+    return c->weights_saturate ? 1 : 0;
+}
+
 void mtts_destroy(mtts_ctx* c) {
     if (!c) return;
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1008,6 +1044,7 @@ int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, con
     DecBufs d;
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
+    RET_IF(begin_call(c, d_ws, s));
     const int nf = c->cfg.n_feats;
     RET_IF(build_frames(c, d, d_mask, nullptr, T, s));
     LAUNCH(c, 2, 0, s, launch_fill_cols(d.xmu, B * T, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
@@ -1038,6 +1075,7 @@ static int solve_core(mtts_ctx* c, const float* d_x0, const float* d_mu, const f
     DecBufs d;
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
+    RET_IF(begin_call(c, d_ws, s));
     const int nf = c->cfg.n_feats, M = B * T;
     RET_IF(build_frames(c, d, d_mask, d_y_len, T_src, s));
     // state rows: x | mu | zero pad.  z = mu + noise when use_mu_prior (reference flow_matching.py:52-55)
@@ -1121,6 +1159,7 @@ static void plan_encoder(const mtts_ctx* c, int B, int Tx, WS& ws, EncBufs& e) {
     const mtts_config& g = c->cfg;
     const size_t M = (size_t)B * Tx;
     const int nch = g.enc_channels, Hd = nch + g.spk_emb_dim, F = g.dp_filter;
+    (void)ws.bytes(256);                 // header: the call's range flag (begin_call)
     e.X0 = ws.f(M * nch); e.P1 = ws.f(M * nch); e.P2 = ws.f(M * nch); e.Y = ws.f(M * std::max(nch, F));
     e.H = ws.f(M * Hd); e.H2 = ws.f(M * Hd); e.QKV = ws.f(M * 3 * Hd); e.ATT = ws.f(M * Hd);
     e.F1 = ws.f(M * g.enc_filter); e.PM = ws.f(M * nch); e.MU = ws.f(M * round_up(g.n_feats, 4));
@@ -1149,6 +1188,7 @@ int mtts_text_encoder_forward(mtts_ctx* c, const int64_t* d_x, const int64_t* d_
     EncBufs e;
     plan_encoder(c, B, Tx, ws, e);
     if (ws.overflow) { set_error("encoder workspace too small"); return -1; }
+    RET_IF(begin_call(c, d_ws, s));
     float* xm = d_x_mask;   // [B,1,Tx] == rows [B*Tx]
     LAUNCH(c, 2, 0, s, launch_seq_mask(d_x_lengths, B, Tx, xm, s));
     LAUNCH(c, 2, 0, s, launch_embedding(d_x, W(c, E.emb.off), M, nch, sqrtf((float)nch), xm, e.X0, nch, s));

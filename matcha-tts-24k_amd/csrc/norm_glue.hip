@@ -308,6 +308,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
     // thread had one 16-byte load in flight and the kernel ran at half the HBM rate)
     constexpr int U = 4;
     using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+    bool range_bad = false;
     for (int r0 = ry; r0 < rows; r0 += RT * U) {
         size_t row[U];
         bool ok[U];
@@ -334,6 +335,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
             if (p.out) *reinterpret_cast<f32x4*>(p.out + row[u] * p.C + c4 * 4) = o;
             if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
                 f16x4 hh, ll;
+                range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && m16[u] != 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float w = o[e] * m16[u];
@@ -357,6 +359,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
             }
         }
     }
+    raise_range_flag(p.range_flag, range_bad);
 }
 
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {

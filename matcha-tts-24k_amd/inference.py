@@ -98,9 +98,40 @@ class MatchaTTSInfer(nn.Module):
             mixed_dur = weight * e_dur if mixed_dur is None else mixed_dur + weight * e_dur
         return mixed_enc, mixed_dur
 
-    @torch.inference_mode()
+    #: what to do when the default arithmetic (fp16 two-term split) met an operand beyond +-65504 (include/mtts.h "range
+    #: guard"): "rerun" the call on the full-range arithmetic (three bf16 terms), "raise", or "ignore" (no flag read, no sync)
+    range_policy = "rerun"
+
     def synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
                    debug=False, z=None, sync_max=None, per_request_padding=False):
+        """``_synthesise`` + the range guard: one read of the sticky device flag per call (a stream synchronisation)."""
+        args = (x, x_lengths, n_timesteps, speaker, voice_mix, scale_correction, length_scale, debug, z, sync_max, per_request_padding)
+        rt = self._rt
+        if rt.use_wide:                       # a previous call or the weights already needed the wide arithmetic
+            return self._synthesise(*args)
+        hip = rt.ready()
+        if hip.gemm_terms() != 2 or self.range_policy == "ignore":
+            return self._synthesise(*args)
+        saturated = hip.weights_saturate()
+        out = None
+        if not saturated:
+            out = self._synthesise(*args)
+            saturated = bool(hip.range_flags().any().item())
+        if not saturated:
+            return out
+        if self.range_policy == "raise" or sync_max is not None:     # (a rank-local rerun would repeat sync_max's collective)
+            raise FloatingPointError("matcha-tts-24k_amd: an operand left the fp16 range (|x| > 65504) in the default split "
+                                     "arithmetic; set model.range_policy = 'rerun' or MTTS_GEMM_TERMS=6")
+        if not getattr(self, "_range_warned", False):
+            print("[matcha-tts-24k_amd] an operand left the fp16 range of the default arithmetic: this model now runs on "
+                  "three-term bf16 products (full fp32 range)")
+            object.__setattr__(self, "_range_warned", True)
+        rt.use_wide = True                     # sticky: a checkpoint that overflows once will do so again
+        return self._synthesise(*args)
+
+    @torch.inference_mode()
+    def _synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
+                    debug=False, z=None, sync_max=None, per_request_padding=False):
         """Text ids -> mel (reference inference.py:78-183).  Returns ``{"mel": [B, n_feats, T_valid_max]}`` (+ the
         reference's debug tensors when ``debug``).
 

@@ -47,22 +47,34 @@ class Runtime:
         self.hp = hp
         self.owner = owner          # root module whose state_dict is the source of truth
         self.hip: Optional[HipModel] = None
+        self.wide: Optional[HipModel] = None      # the same weights on the full-range arithmetic (range guard fallback)
+        self.use_wide = False
         self.dirty = True
         self.mel_mean, self.mel_std = hp.mel_mean, hp.mel_std
+
+    def _load(self, hip: HipModel) -> None:
+        p = next(self.owner.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("matcha-tts-24k_amd: the model must be on a HIP device (model.to('cuda')); "
+                               "there is no CPU path")
+        sd = self.owner.state_dict()
+        hip.load_state_dict(sd, p.device)
+        # denormalisation constants come from the checkpoint's buffers (reference inference.py:54-55,172)
+        self.mel_mean, self.mel_std = float(sd["mel_mean"]), float(sd["mel_std"])
 
     def ready(self) -> HipModel:
         if self.hip is None:
             self.hip = HipModel(self.hp)
         if self.dirty:
-            p = next(self.owner.parameters())
-            if not p.is_cuda:
-                raise RuntimeError("matcha-tts-24k_amd: the model must be on a HIP device (model.to('cuda')); "
-                                   "there is no CPU path")
-            sd = self.owner.state_dict()
-            self.hip.load_state_dict(sd, p.device)
-            # denormalisation constants come from the checkpoint's buffers (reference inference.py:54-55,172)
-            self.mel_mean, self.mel_std = float(sd["mel_mean"]), float(sd["mel_std"])
+            self._load(self.hip)
+            self.wide, self.use_wide = None, False       # new weights: back to the default arithmetic until it overflows
             self.dirty = False
+        if self.use_wide:
+            if self.wide is None:
+                # three exact bf16 terms per operand: the fp32 exponent range, twice the MFMA products of the default
+                self.wide = HipModel(self.hp, terms=6)
+                self._load(self.wide)
+            return self.wide
         return self.hip
 
 

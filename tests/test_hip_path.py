@@ -439,6 +439,48 @@ def test_per_request_padding_on_folded_rows(tiny, prod, synthetic, dev):
         assert maxabs(folded["mel"], full["mel"]) < 1e-4
 
 
+# ------------------------------------------------------------------------------------------------ range guard
+def test_range_guard_reruns_on_full_range_arithmetic(hparams, synthetic, oracle, dev):
+    """The default arithmetic splits operands into fp16 terms and saturates beyond +-65504 (include/mtts.h "range guard").
+    Weights scaled so that one FeedForward's hidden layer reaches ~1e5 (first projection x 4e4, second / 4e4: the network's
+    function is otherwise ordinary): the sticky device flag must fire, `raise` must raise, `ignore` must produce the saturated
+    (wrong) mel, and the default `rerun` must match the oracle on the same weights."""
+    hp = hparams.prod_v20(n_spks=1)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    k = "decoder.estimator.mid_blocks.0.1.0.ff.net."
+    sd[k + "0.proj.weight"] = sd[k + "0.proj.weight"] * 4e4
+    sd[k + "0.proj.bias"] = sd[k + "0.proj.bias"] * 4e4
+    sd[k + "0.alpha"] = sd[k + "0.alpha"] - 10.0           # exp(alpha) small: the snake term stays a smooth function of the hidden value
+    sd[k + "2.weight"] = sd[k + "2.weight"] / 4e4
+    model = make_model(hp, sd, dev)
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 16, seed=77)
+    z = synthetic.cpu_noise((1, 100, 80)).to(dev)
+    model.decoder.solver = "euler"
+    with torch.inference_mode():
+        ref = oracle.synthesise(sd, hp, x, x_len, 2, speaker=0, solver="euler", z=z.cpu())
+    model.range_policy = "ignore"
+    bad = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    assert bool(model.hip.range_flags().any().item())
+    assert maxabs(bad["mel"], ref["mel"]) > 1e-2
+    model.range_policy = "raise"
+    with pytest.raises(FloatingPointError):
+        model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    model.range_policy = "rerun"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    assert model.hip.gemm_terms() == 6                      # the runtime switched to the three-term bf16 context
+    assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
+    again = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    assert torch.equal(out["mel"], again["mel"])
+
+
+def test_range_guard_is_quiet_on_ordinary_weights(prod, synthetic, dev):
+    hp, sd, model = prod
+    x, x_len, _ = synthetic.make_inputs(hp, 2, 40, seed=3)
+    model.decoder.solver = "euler"
+    model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0)
+    assert not bool(model.hip.range_flags().any().item()) and model.hip.gemm_terms() == 2 and not model.hip.weights_saturate()
+
+
 # ------------------------------------------------------------------------------------------------ duration predictor live
 @pytest.mark.parametrize("tag,which", [("dp_tiny", "tiny"), ("dp_prod", "prod")])
 def test_duration_predictor_live_vs_golden(tag, which, hparams, synthetic, dev):

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Experiment: one batch of B utterances as S independent sub-batches on S HIP streams (utterances are independent, so the
+sub-batches' kernels can fill each other's ramp-up / tail / inter-kernel gaps).  python tools/stream_split.py [--batch 32]"""
+import argparse
+import importlib
+import sys
+import threading
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+PKG = "matcha-tts-24k_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--splits", default="1,2,4")
+    ap.add_argument("--threads", type=int, default=1)
+    args = ap.parse_args()
+    hparams = importlib.import_module(PKG + ".hparams")
+    synthetic = importlib.import_module(PKG + ".synthetic")
+    inference = importlib.import_module(PKG + ".inference")
+    dev = torch.device("cuda")
+    hp = hparams.prod_v20(n_spks=1)
+    model = inference.MatchaTTSInfer(**hp.as_reference_kwargs())
+    model.load_state_dict(synthetic.make_state_dict(hp, seed=7), strict=True)
+    model = model.to(dev).eval()
+    model.decoder.solver = "euler"
+    x, x_len, _ = synthetic.make_inputs(hp, args.batch, 128, seed=1234)
+    x, x_len = x.to(dev), x_len.to(dev)
+    for S in [int(v) for v in args.splits.split(",")]:
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        per = args.batch // S
+
+        def part(i):
+            with torch.cuda.stream(streams[i]):
+                model.synthesise(x[i * per:(i + 1) * per], x_len[i * per:(i + 1) * per], 10, speaker=0)
+
+        def step():
+            if args.threads and S > 1:
+                th = [threading.Thread(target=part, args=(i,)) for i in range(S)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+            else:
+                for i in range(S):
+                    part(i)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        print(f"B={args.batch} split into {S} x {per} on {S} stream(s), threads={args.threads}: {el*1e3:.2f} ms/step "
+              f"{args.batch*320/el:.0f} frames/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
