@@ -69,7 +69,7 @@ static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
 static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
     GnApplyArgs a = a0;
     a.range_flag = c->cur_flag;
-    RET_IF(run_gn_apply(c, a, s));
+    LAUNCH(c, 2, 0, s, launch_gn_apply(a, s));
     return 0;
 }
 // The sticky range flag of a call = the first word of its workspace, cleared here (include/mtts.h "range guard").
