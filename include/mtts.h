@@ -241,7 +241,12 @@ int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_
  * clear it on entry): read it back after the call; non-zero = rerun on a context whose arithmetic has the fp32 range
  * (mtts_set_arithmetic(ctx, 6): three bf16 terms).  The Python mirror does this in synthesise().
  * mtts_set_arithmetic: products per fp32 multiply-accumulate as for mtts_gemm_f32's `terms` (0, 2, 3, 6; 1 = the opt-in fp16
- * mode), overriding MTTS_GEMM_TERMS; call before mtts_weights_bytes / mtts_upload_weights (it invalidates the packed image).
+ * mode on P16 images), overriding MTTS_GEMM_TERMS; call before mtts_weights_bytes / mtts_upload_weights (it invalidates the
+ * packed image).  16 = the 16-BIT STORAGE MODE of BASELINE config #3 (the arithmetic torch.autocast gives the reference on its
+ * GPU, reference matcha/inference.py:238): every activation image of the estimator and its weight planes are single fp16
+ * planes (2 bytes per element, half the operand traffic), one MFMA per multiply-accumulate, fp32 accumulation, fp32
+ * GroupNorm / LayerNorm statistics and ODE state; the text encoder and duration predictor keep the fp32-equivalent split
+ * (durations must not move).  Not inside the 1e-3 bar: its measured mel error is reported beside its throughput.
  * mtts_weights_saturate: 1 if a WEIGHT exceeds the fp16 range in the fp16-split mode (decided while packing). */
 int mtts_set_arithmetic(mtts_ctx* ctx, int terms);
 int mtts_weights_saturate(mtts_ctx* ctx);
@@ -249,7 +254,7 @@ int mtts_weights_saturate(mtts_ctx* ctx);
 /* ---------------------------------------------------------------- measurement */
 
 /* GEMM arithmetic of a context (NULL: the library default): 0 native fp32 MFMA, 2 fp16 two-term split (default),
- * 6 bf16 three-term split, 3 bf16 two-term split -- see mtts_gemm_f32. */
+ * 6 bf16 three-term split, 3 bf16 two-term split -- see mtts_gemm_f32; 1 / 16 = the fp16 modes of mtts_set_arithmetic. */
 int mtts_gemm_terms(mtts_ctx* ctx);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline line).

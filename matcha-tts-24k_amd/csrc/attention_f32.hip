@@ -52,8 +52,10 @@ __device__ __forceinline__ f16x4 tr_read4(const _Float16* lds_ptr) {
 }
 
 // ONE (with P16): the opt-in fp16 mode -- heads x heads products only (see gemm_p16.hip).
-template <int NW, bool P16, bool ONE = false>
+// HALF (with P16 and ONE): q|k|v and the output are H16 images (AttnArgs::half16) -- a head is 64 contiguous halves.
+template <int NW, bool P16, bool ONE = false, bool HALF = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
+    static_assert(!HALF || (P16 && ONE), "H16 I/O runs the single-product loop");
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
     constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
@@ -92,17 +94,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                                            // them by the mask afterwards (text_encoder.py:236-237), so their values are don't-care
     const float scale2 = p.scale * LOG2E;  // softmax in the log2 domain: exp(x) = exp2(x * log2 e), folded into the score FMA
     f16x8 qh[4], ql[4];
-    const _Float16* q16 = p.qkv16 + head * (2 * AT_D);                       // head h = groups 2h, 2h+1 of the q section
-    const _Float16* k16 = q16 + 2 * p.H * AT_D;
-    const _Float16* v16 = q16 + 4 * p.H * AT_D;
+    const _Float16* q16 = p.qkv16 + head * ((HALF ? 1 : 2) * AT_D);          // head h = groups 2h, 2h+1 of the q section
+    const _Float16* k16 = q16 + (HALF ? 1 : 2) * p.H * AT_D;
+    const _Float16* v16 = q16 + (HALF ? 2 : 4) * p.H * AT_D;
     if constexpr (P16) {
         const _Float16* qrow = q16 + (rowbase + (q_in ? qi : 0)) * (size_t)p.ld16;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            const _Float16* src = qrow + (kb >> 1) * 64 + (kb & 1) * 16 + 8 * h;
+            const _Float16* src = HALF ? qrow + 16 * kb + 8 * h : qrow + (kb >> 1) * 64 + (kb & 1) * 16 + 8 * h;
             qh[kb] = q_in ? *reinterpret_cast<const f16x8*>(src) : z;
-            ql[kb] = q_in ? *reinterpret_cast<const f16x8*>(src + 32) : z;
+            ql[kb] = (q_in && !HALF) ? *reinterpret_cast<const f16x8*>(src + 32) : z;
         }
     } else
 #pragma unroll
@@ -143,7 +145,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
             const size_t row = rowbase + (r_in[sp] ? key : 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if constexpr (P16) {
+                if constexpr (HALF) {          // 8 chunks of 8 halves per head: this thread's are (tid&3) and (tid&3) + 4
+                    if (c < 2) {
+                        rk[sp][c] = *reinterpret_cast<const f32x4*>(k16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
+                        rv[sp][c] = *reinterpret_cast<const f32x4*>(v16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
+                    }
+                } else if constexpr (P16) {
                     rk[sp][c] = *reinterpret_cast<const f32x4*>(k16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
                     rv[sp][c] = *reinterpret_cast<const f32x4*>(v16 + row * p.ld16 + ((tid & 3) + 4 * c) * 8);
                 } else {
@@ -161,7 +168,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
         for (int sp = 0; sp < SP; ++sp) {
             const int r = srow + SROWS * sp;
-            if constexpr (P16) {
+            if constexpr (HALF) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {      // chunk (tid&3) + 4c = dims 8 (tid&3) + 32 c ..+7 of the one plane
+                    const int d = 32 * c + 8 * (tid & 3);
+                    *reinterpret_cast<f32x4*>(Ks + r * AT_KS + d) = r_in[sp] ? rk[sp][c] : zero;
+                    *reinterpret_cast<f32x4*>(Vs + (c * AT_K + r) * 32 + 8 * (tid & 3)) = r_in[sp] ? rv[sp][c] : zero;
+                }
+            } else if constexpr (P16) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {      // chunk (tid&3) + 4c: plane c&1 (head / residual), dims 32 (c>>1) + 8 (tid&3) ..+7
                     const int plane = c & 1, d = 32 * (c >> 1) + 8 * (tid & 3);
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
     bool range_bad = false;
     if (P16) {
         if (q_in) {
-            _Float16* op = p.out16 + (rowbase + qi) * (size_t)p.ldo16 + head * (2 * AT_D);
+            _Float16* op = p.out16 + (rowbase + qi) * (size_t)p.ldo16 + head * ((HALF ? 1 : 2) * AT_D);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -316,8 +330,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                         hh[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
                         ll[e] = (_Float16)fminf(fmaxf((v - (float)hh[e]) * p.out_lscale, -65504.f), 65504.f);
                     }
-                    *reinterpret_cast<f16x4*>(op + t * 64 + 8 * g4 + 4 * h) = hh;
-                    *reinterpret_cast<f16x4*>(op + t * 64 + 32 + 8 * g4 + 4 * h) = ll;
+                    if constexpr (HALF) {
+                        *reinterpret_cast<f16x4*>(op + t * 32 + 8 * g4 + 4 * h) = hh;
+                    } else {
+                        *reinterpret_cast<f16x4*>(op + t * 64 + 8 * g4 + 4 * h) = hh;
+                        *reinterpret_cast<f16x4*>(op + t * 64 + 32 + 8 * g4 + 4 * h) = ll;
+                    }
                 }
         }
         raise_range_flag(p.range_flag, range_bad);
@@ -338,7 +356,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const bool p16 = a.qkv16 != nullptr;
-    if (p16 ? (!a.out16 || a.D != AT_D || a.ld16 < 6 * a.H * AT_D || (a.ld16 & 7) || a.ldo16 < 2 * a.H * AT_D || (a.ldo16 & 3))
+    const int ew = a.half16 ? 1 : 2;
+    if (a.half16 && !p16) return hipErrorInvalidValue;
+    if (p16 ? (!a.out16 || a.D != AT_D || a.ld16 < 3 * ew * a.H * AT_D || (a.ld16 & 7) || a.ldo16 < ew * a.H * AT_D || (a.ldo16 & 3))
             : (!a.qkv || !a.out))
         return hipErrorInvalidValue;
     if (a.B <= 0 || a.T <= 0 || a.H <= 0) return hipErrorInvalidValue;
@@ -351,11 +371,13 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     static const int env_nw = [] { const char* e = getenv("MTTS_ATTN_NW"); return e ? atoi(e) : 0; }();     // A/B runs only
     const bool use128 = env_nw == 4 || (env_nw == 0 && blocks128 >= 768 && waste128 < 0.1);
     if (use128) {
-        if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        else if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
     } else {
-        if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        else if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else if (p16) hipLaunchKernelGGL((attention_f32_kernel<2, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<2, false>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
     }

@@ -117,9 +117,14 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 }
                 if constexpr (RESK == 2) {
                     const int ncl = col_ok ? nc : 0;
-                    const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
-                    L.r16h[u] = *reinterpret_cast<const f16x4*>(q);
-                    L.r16l[u] = *reinterpret_cast<const f16x4*>(q + 32);
+                    if (p.half16) {
+                        L.r16h[u] = *reinterpret_cast<const f16x4*>(p.res16 + (size_t)r * p.ldr16 + ncl);
+                        L.r16l[u] = f16x4{0, 0, 0, 0};
+                    } else {
+                        const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
+                        L.r16h[u] = *reinterpret_cast<const f16x4*>(q);
+                        L.r16l[u] = *reinterpret_cast<const f16x4*>(q + 32);
+                    }
                 }
             }
         };
@@ -170,9 +175,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                             h[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
                             l[e] = (_Float16)fminf(fmaxf((v - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
                         }
-                        _Float16* o16 = p.out16 + (size_t)L.orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
-                        *reinterpret_cast<f16x4*>(o16) = h;
-                        *reinterpret_cast<f16x4*>(o16 + 32) = l;
+                        if (p.half16) {
+                            *reinterpret_cast<f16x4*>(p.out16 + (size_t)L.orow[u] * p.ld16 + nc) = h;
+                        } else {
+                            _Float16* o16 = p.out16 + (size_t)L.orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
+                            *reinterpret_cast<f16x4*>(o16) = h;
+                            *reinterpret_cast<f16x4*>(o16 + 32) = l;
+                        }
                     }
                 }
                 if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row (N % 64 == 0): the 16 lanes lane&15 hold them

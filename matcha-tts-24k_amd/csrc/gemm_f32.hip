@@ -552,6 +552,13 @@ hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hi
     hipLaunchKernelGGL(split_panel_f16_kernel, dim3(grid), dim3(256), 0, s, panel, n, static_cast<_Float16*>(planes));
     return hipGetLastError();
 }
+void panel_h16_host(const float* panel, size_t n, uint16_t* plane) {
+    for (size_t i = 0; i < n; ++i) {
+        const float x = panel[i];
+        const _Float16 h = (_Float16)(x < -65504.f ? -65504.f : (x > 65504.f ? 65504.f : x));
+        memcpy(&plane[i], &h, 2);
+    }
+}
 void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes) {
     for (size_t i = 0; i < n; ++i) {
         const float x = panel[i];

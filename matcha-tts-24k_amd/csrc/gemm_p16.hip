@@ -50,8 +50,14 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // while the MFMAs of tile kt run on the registers loaded one iteration earlier, so a k-step costs max(MFMA time, LDS + DMA
 // issue) instead of their sum; tile kt's stage is free as soon as the step begins and takes the DMA of tile kt+NST (NST tiles
 // ahead with NST stages).  Costs a second fragment set in registers (BM = 64: 48 VGPRs).
-template <int BM, bool LN, int NST, bool ONE, bool M16, bool PIPE = false>
+// MODE: 0 = P16 operands, three products per MAC (the default, fp32-equivalent); 1 = P16 operands, heads x heads only (the
+// opt-in fp16 mode, ONE); 2 = H16 operands (GemmArgs::half16): a 128-byte line holds 64 k of one fp16 plane, a k-step is 64
+// deep and its two 32-k halves are what the head / residual chunks of a P16 line are to the DMA and the fragment reads.
+template <int BM, bool LN, int NST, int MODE, bool M16, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
+    constexpr bool ONE = MODE == 1;
+    constexpr bool HALF = MODE == 2;
+    constexpr int KSTEP = HALF ? 64 : 32;                  // k elements per 128-byte line
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
     constexpr int STAGE = p16_stage_bytes(BM);
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE array: stages | epilogue tile | row statistics
@@ -93,7 +99,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     for (int j = 0; j < 4; ++j) {
         const int pw = wave * 4 + j;
         const int chunk = (lane & 7) ^ (((pw & 1) * 4 + (lane >> 4)) & 7);
-        wsrc[j] = reinterpret_cast<const _Float16*>(p.w16) + (size_t)(n0 + pw * 8 + (lane >> 3)) * Kp * 2 + chunk * 8;
+        wsrc[j] = HALF ? reinterpret_cast<const _Float16*>(p.w16h) + (size_t)(n0 + pw * 8 + (lane >> 3)) * Kp + chunk * 8
+                       : reinterpret_cast<const _Float16*>(p.w16) + (size_t)(n0 + pw * 8 + (lane >> 3)) * Kp * 2 + chunk * 8;
     }
     // The K axis is a sequence of runs, one per (tap, channel segment); inside a run every k-step only advances the source
     // pointers by one 128-B group, so the per-lane address arithmetic (tap shift, sequence bounds, segment base) is done once
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
             asrc[j] = ok ? src + (size_t)(a_base[j] + tin) * ld + a_chunk[j] : g_p16_zero_line + a_chunk[j];
             astep[j] = ok ? 64 : 0;                                      // the zero line is re-read, not walked
         }
-        run_left = (seg1 ? p.c1 : p.c0) >> 5;
+        run_left = (seg1 ? p.c1 : p.c0) / KSTEP;
     };
     auto issue = [&](int buf) {
         char* st = lds + buf * STAGE;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 
     // operand fragment: lane (r = lane&15, q = lane>>4) holds k = 8q .. 8q+7 of row r -- head chunk q, residual chunk 4 + q
     const int fr = lane & 15, fq = lane >> 4, f8 = (fr >> 1) & 7;
-    const int nk = Kp / GEMM_BK;
+    const int nk = Kp / KSTEP;
     auto compute16 = [&](const char* stage) {
         const char* sa = stage + (wm * (BM / 2) + fr) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
@@ -176,7 +183,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (!ONE) {
+                if constexpr (HALF) {          // second 32-k half of the line
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bl[j], acc[i][j], 0, 0, 0);
+                } else if constexpr (!ONE) {
                     accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
                     accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
                 }
@@ -204,7 +213,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (!ONE) {
+                if constexpr (HALF) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+                } else if constexpr (!ONE) {
                     accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
                     accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
                 }
@@ -215,24 +226,24 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         const char* sa = stage + (wm * (BM / 2) + fr32) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr32) * 128;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < (HALF ? 4 : 2); ++kb) {      // H16: the line's eight 16-byte chunks are four 16-k blocks of one plane
             const int sh = ((2 * kb + fh32) ^ f832) * 16, sl = ((4 + 2 * kb + fh32) ^ f832) * 16;
             f16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sh);
-                if constexpr (!ONE) al[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sl);
+                if constexpr (MODE == 0) al[i] = *reinterpret_cast<const f16x8*>(sa + i * 32 * 128 + sl);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sh);
-                if constexpr (!ONE) bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sl);
+                if constexpr (MODE == 0) bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 32 * 128 + sl);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if constexpr (!ONE) {
+                    if constexpr (MODE == 0) {
                         accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx32[i][j], 0, 0, 0);
                         accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx32[i][j], 0, 0, 0);
                     }
@@ -414,10 +425,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
 // at most one workgroup per CU are latency-bound and lose 4 % with the longer 16x16 issue sequence; B <= 8 serving shapes).
-template <int BM, bool LN, int NST, bool ONE, bool M16, bool PIPE = false>
+template <int BM, bool LN, int NST, int MODE, bool M16, bool PIPE = false>
 static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST, ONE, M16, PIPE>;
+    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16, PIPE>;
     constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -430,21 +441,25 @@ static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BM, bool LN, int NST, bool ONE>
+template <int BM, bool LN, int NST, int MODE>
 static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     // MFMA shape by pipeline depth: 16x16x32 wherever a CU holds more than one workgroup, 32x32x16 on the 4-stage ring (see above)
-    if constexpr (NST == 4) return launch_p16_shape<BM, LN, NST, ONE, false>(a, s);
-    else if constexpr (BM == 64) {
-        // 64-row tiles: MTTS_P16_PIPE=1 double-buffers the operand fragments in registers (PIPE).  Opt-in: measured 31.2 vs 30.5
-        // ms/step at B = 32 (r02) -- the loop is bound by operand delivery (LDS-DMA issue), not by the fragment reads
+    if constexpr (NST == 4) return launch_p16_shape<BM, LN, NST, MODE, false>(a, s);
+#ifdef MTTS_BUILD_PIPE_VARIANT
+    else if constexpr (BM == 64 && MODE == 0) {
+        // 64-row tiles: MTTS_P16_PIPE=1 double-buffers the operand fragments in registers (PIPE).  Not built by default: measured
+        // 31.2 vs 30.5 ms/step at B = 32 (r02) -- the loop is bound by operand delivery (LDS-DMA issue), not by the fragment reads
         static const bool pipe = [] { const char* e = getenv("MTTS_P16_PIPE"); return e && e[0] == '1'; }();
-        return pipe ? launch_p16_shape<BM, LN, NST, ONE, true, true>(a, s) : launch_p16_shape<BM, LN, NST, ONE, true>(a, s);
-    } else return launch_p16_shape<BM, LN, NST, ONE, true>(a, s);
+        return pipe ? launch_p16_shape<BM, LN, NST, MODE, true, true>(a, s) : launch_p16_shape<BM, LN, NST, MODE, true>(a, s);
+    }
+#endif
+    else return launch_p16_shape<BM, LN, NST, MODE, true>(a, s);
 }
 
 template <int BM, bool LN, int NST = 2>
 static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
-    return a.fast16 ? launch_p16_one<BM, LN, NST, true>(a, s) : launch_p16_one<BM, LN, NST, false>(a, s);
+    if (a.half16) return launch_p16_one<BM, LN, NST, 2>(a, s);
+    return a.fast16 ? launch_p16_one<BM, LN, NST, 1>(a, s) : launch_p16_one<BM, LN, NST, 0>(a, s);
 }
 
 // Block-tile height and pipeline depth for a shape (also what gemm_p16_wave_rows reports to callers that must match it).
@@ -479,12 +494,13 @@ int gemm_p16_wave_rows(const GemmArgs& a) {
 
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     // shape contract (the kernel indexes without further checks)
-    if (!a.a16_0 || !a.w16 || a.terms != 2 || (!a.out && !a.out16) || a.N <= 0 || (a.N & 3) || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0)
+    const int kq = a.half16 ? 64 : GEMM_BK, ew = a.half16 ? 1 : 2;      // k elements per 128-byte line; halves per element
+    if (!a.a16_0 || (a.half16 ? !a.w16h : !a.w16) || a.terms != 2 || (!a.out && !a.out16) || a.N <= 0 || (a.N & 3) || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0)
         return hipErrorInvalidValue;
-    if (a.ntaps < 1 || a.ntaps > MAX_TAPS || a.ktap <= 0 || a.ktap % GEMM_BK != 0) return hipErrorInvalidValue;
-    if ((a.c0 % GEMM_BK) || (a.c1 % GEMM_BK) || a.c0 + a.c1 != a.ktap) return hipErrorInvalidValue;   // images are physically padded
+    if (a.ntaps < 1 || a.ntaps > MAX_TAPS || a.ktap <= 0 || a.ktap % kq != 0) return hipErrorInvalidValue;
+    if ((a.c0 % kq) || (a.c1 % kq) || a.c0 + a.c1 != a.ktap) return hipErrorInvalidValue;   // images are physically padded
     if ((a.a16_1 == nullptr) != (a.c1 == 0)) return hipErrorInvalidValue;
-    if (a.lda16_0 < 2 * a.c0 || (a.lda16_0 & 7) || (a.a16_1 && (a.lda16_1 < 2 * a.c1 || (a.lda16_1 & 7)))) return hipErrorInvalidValue;
+    if (a.lda16_0 < ew * a.c0 || (a.lda16_0 & 7) || (a.a16_1 && (a.lda16_1 < ew * a.c1 || (a.lda16_1 & 7)))) return hipErrorInvalidValue;
     if (a.a_mask) return hipErrorInvalidValue;                       // P16 images are written already masked
     if ((a.a_mean == nullptr) != (a.a_rstd == nullptr)) return hipErrorInvalidValue;
     if (a.a_part && (a.a_mean || a.a_nparts <= 0)) return hipErrorInvalidValue;
@@ -492,8 +508,8 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (ln && (!a.wsum || a.ntaps != 1 || a.in_stride != 1 || a.tap_off[0] != 0 || a.T_in != a.T_out)) return hipErrorInvalidValue;
     if (a.out && (a.ldc & 3)) return hipErrorInvalidValue;
     if (a.res && (a.ldr & 3)) return hipErrorInvalidValue;
-    if (a.res16 && (a.res || (a.N % 32) || a.ldr16 < 2 * a.N || (a.ldr16 & 3))) return hipErrorInvalidValue;
-    if (a.out16 && ((a.N % 32) || a.ld16 < 2 * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
+    if (a.res16 && (a.res || (a.N % 32) || a.ldr16 < ew * a.N || (a.ldr16 & 3))) return hipErrorInvalidValue;
+    if (a.out16 && ((a.N % 32) || a.ld16 < ew * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
     if (a.gn_stats) {
@@ -523,7 +539,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ fp32 <-> P16
 __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C, int C_valid,
-                              _Float16* __restrict__ out, int ld16, float lscale, unsigned int* range_flag) {
+                              _Float16* __restrict__ out, int ld16, float lscale, unsigned int* range_flag, bool half16) {
     const int c4n = C >> 2;
     const size_t n = (size_t)M * c4n;
     bool range_bad = false;
@@ -539,20 +555,24 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
             h[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
             l[e] = (_Float16)fminf(fmaxf((v[e] - (float)h[e]) * lscale, -65504.f), 65504.f);
         }
-        _Float16* o = out + (size_t)row * ld16 + (c >> 5) * 64 + (c & 31);
-        *reinterpret_cast<f16x4*>(o) = h;
-        *reinterpret_cast<f16x4*>(o + 32) = l;
+        if (half16) {
+            *reinterpret_cast<f16x4*>(out + (size_t)row * ld16 + c) = h;
+        } else {
+            _Float16* o = out + (size_t)row * ld16 + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<f16x4*>(o) = h;
+            *reinterpret_cast<f16x4*>(o + 32) = l;
+        }
     }
     raise_range_flag(range_flag, range_bad);
 }
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s, unsigned int* range_flag) {
-    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || C_valid > C || (C_valid & 3) || ld < C_valid || ld16 < 2 * C || (ld16 & 3))
+                         hipStream_t s, unsigned int* range_flag, bool half16) {
+    if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || C_valid > C || (C_valid & 3) || ld < C_valid || ld16 < (half16 ? 1 : 2) * C || (ld16 & 3))
         return hipErrorInvalidValue;
     const size_t n = (size_t)M * (C >> 2);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale, range_flag);
+    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale, range_flag, half16);
     return hipGetLastError();
 }
 __global__ void from_p16_kernel(const _Float16* __restrict__ x, int ld16, int M, int C, float inv_lscale, float* __restrict__ out, int ld) {

@@ -87,6 +87,11 @@ struct GemmArgs {
     const int* gnr_nextra = nullptr;      // folded padding (GnApplyArgs::nextra / bias_stats): copies of the producing conv's bias
     const float* gnr_bias_stats = nullptr;//   row that belong to the statistics without existing as rows
     bool fast16 = false;              // P16 kernel only: heads x heads product alone (fp16 operands, fp32 accumulate), see MTTS_GEMM_TERMS=1
+    // 16-bit storage mode (BASELINE config #3; mtts_set_arithmetic(ctx, 16)): every image named "16" above is an "H16" image --
+    // ONE fp16 plane, rows of C halves (C % 64 == 0: a 128-byte line = 64 channels), 2 bytes per element -- the weight plane is
+    // w16h [Np][Kp] halves, and a MAC is one v_mfma_f32_16x16x32_f16 with fp32 accumulation.  Row strides stay in halves.
+    bool half16 = false;
+    const void* w16h = nullptr;
     // fp16-split arithmetic only: set to 1 (sticky, atomicOr) when an operand this launch splits -- an A element while staging
     // (gemm_f32.hip, terms 2) or an out16 element (epilogue) -- lies beyond +-65504 and saturates.  Null = no check.
     unsigned int* range_flag = nullptr;
@@ -96,7 +101,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by 
 int gemm_p16_wave_rows(const GemmArgs& a);                          // rows of a wave tile (BM/2) launch_gemm_p16 will use for these shapes
 // fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s, unsigned int* range_flag = nullptr);   // channels [C_valid, C) are written as zeros
+                         hipStream_t s, unsigned int* range_flag = nullptr, bool half16 = false);   // half16: H16 image, lscale unused   // channels [C_valid, C) are written as zeros
 hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
@@ -119,6 +124,7 @@ hipError_t launch_pack_weight(const float* w, int N, int C, int ntaps, float* ds
 void split_panel_host(const float* panel, size_t n, uint16_t* planes);
 hipError_t launch_split_panel(const float* panel, size_t n, void* planes, hipStream_t s);
 void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes);
+void panel_h16_host(const float* panel, size_t n, uint16_t* plane);      // the fp16 head plane alone, same element order as the panel
 hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hipStream_t s);
 
 struct AttnArgs {
@@ -137,6 +143,7 @@ struct AttnArgs {
                                   // identical padded frames (reference bias +0 each)
     bool fast16 = false;          // P16 I/O only: single fp16 product per MAC (no residual terms)
     unsigned int* range_flag = nullptr;   // P16 output: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
+    bool half16 = false;          // q|k|v and the output are H16 images (GemmArgs::half16): a head = 64 contiguous halves
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
@@ -200,6 +207,7 @@ struct GnApplyArgs {
     int tile_rows = 0;                // rows per wave tile of that GEMM (gemm_p16_wave_rows); T % tile_rows == 0
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
     unsigned int* range_flag = nullptr;   // out16: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
+    bool half16 = false;                  // out16 is an H16 image (GemmArgs::half16)
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 

@@ -19,6 +19,7 @@ struct Panel {
     size_t w16 = 0;            // bf16 split planes [3][Np][Kp] (offset in floats), present when the context uses a split mode
     bool has_bias = false;
     size_t wsum = 0;           // [Np] row sums of the panel (fp16-split mode): LayerNorm in the P16 GEMM's epilogue
+    size_t wh16 = 0;           // 16-bit storage mode: the fp16 head plane alone [Np][Kp] halves (offset in floats)
     int N = 0, C = 0, ntaps = 1, ktap = 0;
 };
 struct Vec { size_t off = 0; int n = 0; };
@@ -81,6 +82,9 @@ struct mtts_ctx {
     unsigned int* cur_flag = nullptr;   // range flag of the call being enqueued: first word of its workspace (include/mtts.h)
     bool weights_saturate = false;      // fp16-split mode: a weight beyond +-65504 was met while packing
     const int* d_tlen = nullptr;  // per-utterance frame limits of the next estimator calls (mtts_set_frame_limits), device [B]
+    bool half16 = false;          // 16-bit storage mode (mtts_set_arithmetic(ctx, 16) / MTTS_GEMM_TERMS=16): the estimator's images are
+                                  // single fp16 planes, one MFMA per MAC (BASELINE config #3); everything else as for terms 2
+    bool half_now = false;        // set while the estimator's launches are being enqueued in that mode
     bool fast16 = false;          // MTTS_GEMM_TERMS=1 at mtts_create: the estimator's P16 kernels multiply the fp16 heads only
     bool p16_on = true;           // fp16-split mode: activations as P16 images between kernels (MTTS_P16=0 at mtts_create disables)
     mtts::DecW dec;

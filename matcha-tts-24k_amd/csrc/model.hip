@@ -57,18 +57,21 @@ static int prof_end(mtts_ctx* c, hipStream_t s) {
 static int run_gemm(mtts_ctx* c, const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.range_flag = c->cur_flag;
+    a.half16 = c->half_now && a.a16_0 != nullptr;
     LAUNCHB(c, 0, gemm_flops(a), gemm_bytes(a), s, launch_gemm(a, s));
     return 0;
 }
 static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.range_flag = c->cur_flag;
+    a.half16 = c->half_now && a.qkv16 != nullptr;
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
 static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
     GnApplyArgs a = a0;
     a.range_flag = c->cur_flag;
+    a.half16 = c->half_now && a.out16 != nullptr;
     LAUNCH(c, 2, 0, s, launch_gn_apply(a, s));
     return 0;
 }
@@ -161,9 +164,16 @@ struct Packer {
             const int Np = round_up(p.N, GEMM_BN);
             const size_t Kp = (size_t)p.ntaps * p.ktap;
             p.wsum = alloc(Np);
+            if (c->half16) {      // 16-bit storage mode: the fp16 head plane alone + row sums of the ROUNDED weights (LN epilogue)
+                p.wh16 = alloc((n + 1) / 2);
+                panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
+            }
             for (int r = 0; r < Np; ++r) {
                 double acc = 0.0;
-                for (size_t k = 0; k < Kp; ++k) acc += (double)c->image[p.w + (size_t)r * Kp + k];
+                for (size_t k = 0; k < Kp; ++k) {
+                    const float w = c->image[p.w + (size_t)r * Kp + k];
+                    acc += c->half16 ? (double)(float)(_Float16)fminf(fmaxf(w, -65504.f), 65504.f) : (double)w;
+                }
                 c->image[p.wsum + r] = (float)acc;
             }
         } else split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
@@ -171,7 +181,7 @@ struct Packer {
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
         Panel p;
-        p.N = N; p.C = C; p.ntaps = ntaps; p.ktap = round_up(C, GEMM_BK);
+        p.N = N; p.C = C; p.ntaps = ntaps; p.ktap = round_up(C, c->half16 ? 64 : GEMM_BK);
         const int Np = round_up(N, GEMM_BN);
         const size_t Kp = (size_t)ntaps * p.ktap;
         p.w = alloc((size_t)Np * Kp);
@@ -190,7 +200,7 @@ struct Packer {
         p.N = N_each * parts;
         p.C = C;
         p.ntaps = ntaps;
-        p.ktap = round_up(C, GEMM_BK);
+        p.ktap = round_up(C, c->half16 ? 64 : GEMM_BK);
         const int Np = round_up(p.N, GEMM_BN);
         const size_t Kp = (size_t)ntaps * p.ktap;
         p.w = alloc((size_t)Np * Kp);
@@ -360,7 +370,7 @@ static int pack_all(mtts_ctx* c) {
         for (size_t i = 0; i < D.res.size(); ++i) { D.res[i].tb_off = total; total += mlp_n[i]; }
         D.tb_total = total;
         Panel p;
-        p.N = total; p.C = temb; p.ntaps = 1; p.ktap = round_up(temb, GEMM_BK); p.has_bias = true;
+        p.N = total; p.C = temb; p.ntaps = 1; p.ktap = round_up(temb, c->half16 ? 64 : GEMM_BK); p.has_bias = true;
         p.w = P.alloc((size_t)round_up(total, GEMM_BN) * p.ktap);
         p.b = P.alloc(round_up(total, GEMM_BN));
         for (size_t i = 0; i < D.res.size() && P.ok; ++i) {
@@ -398,6 +408,7 @@ static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
     a.bias = p.has_bias ? W(c, p.b) : nullptr;
     a.wsum = c->gemm_terms == 2 ? W(c, p.wsum) : nullptr;
     a.fast16 = c->fast16;
+    a.w16h = c->half16 ? static_cast<const void*>(W(c, p.wh16)) : nullptr;
     a.N = p.N;
     a.ntaps = p.ntaps;
     a.ktap = p.ktap;
@@ -427,6 +438,7 @@ struct DecBufs {
     float *xmu = nullptr, *xmu2 = nullptr, *vel[4] = {nullptr, nullptr, nullptr, nullptr};
     float *TS = nullptr, *T1 = nullptr, *T2 = nullptr, *T3 = nullptr, *TB = nullptr;
     int ldx = 0, ldv = 0;
+    int ew = 2;                          // halves per image element: 2 = P16 (head + residual), 1 = H16 (16-bit storage mode)
     // frame tables (kernels.h FrameTableArgs), per level: null when every utterance owns all T rows
     int T_true = 0;                      // the reference's padded length; T above is the rows per utterance actually held
     bool folded = false;
@@ -494,11 +506,12 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
             d.S16[l] = reinterpret_cast<_Float16*>(ws.f(Ml * cmax));
         }
         d.H16 = reinterpret_cast<_Float16*>(ws.f(M0 * cmax));
-        d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, GEMM_BK)));
+        d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, 64)));
     }
     d.gnp = ws.f((size_t)B * gn_chunks_max(T) * 8 * 2);
     d.gns = ws.f((M0 / 32 + 1) * (size_t)((cmax + 63) / 64) * 8);
-    d.ldx = round_up(2 * g.n_feats, GEMM_BK);
+    d.ew = (d.p16 && c->half16) ? 1 : 2;
+    d.ldx = round_up(2 * g.n_feats, c->half16 ? 64 : GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
     d.xmu = ws.f(M0 * d.ldx);
     if (n_state > 1) d.xmu2 = ws.f(M0 * d.ldx);
@@ -565,7 +578,7 @@ static int resnet_block(mtts_ctx* c, DecBufs& d, const ResnetW& r, const float* 
     g2.res = d.Rr; g2.ldr = C; g2.out = out; g2.B = B; g2.T = T; g2.C = C;
     if (emit_stats && (C % 64) == 0) {       // for the first transformer block: LayerNorm moments and, in P16 mode, x's image
         g2.stats_out = d.lnp;
-        if (p16_blocks(c, C)) { g2.out16 = d.X16; g2.ld16 = 2 * C; }
+        if (p16_blocks(c, C)) { g2.out16 = d.X16; g2.ld16 = d.ew * C; }
     }
     RET_IF(run_gn_apply(c, g2, s));
     return 0;
@@ -590,33 +603,33 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         _Float16* FF16 = reinterpret_cast<_Float16*>(d.FF);
         GemmArgs q;
         panel_args(c, t.qkv, q); rows_plain(q, B, T);
-        q.a16_0 = d.X16; q.lda16_0 = 2 * C; q.c0 = C; q.a_part = d.lnp; q.a_nparts = C / 64;
-        q.out16 = QKV16; q.ld16 = 6 * inner; q.out_lscale = 1.0f;
+        q.a16_0 = d.X16; q.lda16_0 = d.ew * C; q.c0 = C; q.a_part = d.lnp; q.a_nparts = C / 64;
+        q.out16 = QKV16; q.ld16 = 3 * d.ew * inner; q.out_lscale = 1.0f;
         RET_IF(run_gemm(c, q, s));
         AttnArgs at;
-        at.qkv16 = QKV16; at.ld16 = 6 * inner; at.out16 = ATT16; at.ldo16 = 2 * inner; at.mask = d.kb(lvl);
+        at.qkv16 = QKV16; at.ld16 = 3 * d.ew * inner; at.out16 = ATT16; at.ldo16 = d.ew * inner; at.mask = d.kb(lvl);
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
         at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.klen = d.nr(lvl); at.fast16 = c->fast16;
         RET_IF(run_attn(c, at, s));
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
-        o.a16_0 = ATT16; o.lda16_0 = 2 * inner; o.c0 = inner;
-        o.out16 = d.X16; o.ld16 = 2 * C; o.stats_out = d.lnp;
-        if (d.p16) { o.res16 = d.X16; o.ldr16 = 2 * C; }      // P16 decoder: the residual stream exists only as its image
+        o.a16_0 = ATT16; o.lda16_0 = d.ew * inner; o.c0 = inner;
+        o.out16 = d.X16; o.ld16 = d.ew * C; o.stats_out = d.lnp;
+        if (d.p16) { o.res16 = d.X16; o.ldr16 = d.ew * C; }      // P16 decoder: the residual stream exists only as its image
         else { o.res = x; o.ldr = C; o.out = x; o.ldc = C; }
         RET_IF(run_gemm(c, o, s));
         GemmArgs f1;
         panel_args(c, t.ff1, f1); rows_plain(f1, B, T);
-        f1.a16_0 = d.X16; f1.lda16_0 = 2 * C; f1.c0 = C; f1.a_part = d.lnp; f1.a_nparts = C / 64; f1.act = ACT_SNAKE;
-        f1.p0 = W(c, t.alpha_exp.off); f1.p1 = W(c, t.inv_beta.off); f1.out16 = FF16; f1.ld16 = 8 * C;
+        f1.a16_0 = d.X16; f1.lda16_0 = d.ew * C; f1.c0 = C; f1.a_part = d.lnp; f1.a_nparts = C / 64; f1.act = ACT_SNAKE;
+        f1.p0 = W(c, t.alpha_exp.off); f1.p1 = W(c, t.inv_beta.off); f1.out16 = FF16; f1.ld16 = 4 * d.ew * C;
         RET_IF(run_gemm(c, f1, s));
         GemmArgs f2;
         panel_args(c, t.ff2, f2); rows_plain(f2, B, T);
-        f2.a16_0 = FF16; f2.lda16_0 = 8 * C; f2.c0 = 4 * C;
-        if (d.p16) { f2.res16 = d.X16; f2.ldr16 = 2 * C; }
+        f2.a16_0 = FF16; f2.lda16_0 = 4 * d.ew * C; f2.c0 = 4 * C;
+        if (d.p16) { f2.res16 = d.X16; f2.ldr16 = d.ew * C; }
         else { f2.res = x; f2.ldr = C; f2.out = x; f2.ldc = C; }
-        if (emit_stats) { f2.stats_out = d.lnp; f2.out16 = d.X16; f2.ld16 = 2 * C; }
-        else if (last16) { f2.out16 = last16; f2.ld16 = 2 * C; f2.out16_mask = d.mask[lvl]; }
+        if (emit_stats) { f2.stats_out = d.lnp; f2.out16 = d.X16; f2.ld16 = d.ew * C; }
+        else if (last16) { f2.out16 = last16; f2.ld16 = d.ew * C; f2.out16_mask = d.mask[lvl]; }
         RET_IF(run_gemm(c, f2, s));
         return 0;
     }
@@ -664,7 +677,12 @@ struct FinalOut {   // where the masked velocity goes: out = v * scale (+ res)
 // xin: channels-last state [B*T, ldx] holding x | mu.
 static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s);
 static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const FinalOut& fo, hipStream_t s) {
-    if (d.p16) return decoder_eval_p16(c, d, xin, ev, fo, s);
+    if (d.p16) {
+        c->half_now = d.ew == 1;          // 16-bit storage mode: the estimator's images are H16 (kernels.h GemmArgs::half16)
+        const int r = decoder_eval_p16(c, d, xin, ev, fo, s);
+        c->half_now = false;
+        return r;
+    }
     const mtts_config& g = c->cfg;
     const DecW& D = c->dec;
     const int nl = d.nl, nb = g.dec_n_blocks, B = d.B;
@@ -773,7 +791,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     const float* mask = d.mask[lvl];
     GemmArgs a;
     panel_args(c, r.conv1, a); rows_plain(a, B, T); taps_centered(a, 3);
-    a.a16_0 = in0; a.lda16_0 = 2 * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = 2 * c1; a.c1 = c1;
+    a.a16_0 = in0; a.lda16_0 = d.ew * c0; a.c0 = c0; a.a16_1 = in1; a.lda16_1 = d.ew * c1; a.c1 = c1;
     a.out = d.Y; a.ldc = C;
     const int fr1 = gn_fuse_rows(a, C, 8, T);
     if (fr1) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_nrows = d.nr(lvl); }
@@ -783,18 +801,18 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     if (fr1) { g1.tile_stats = d.gns; g1.tile_rows = fr1; }
     g1.y = d.Y; g1.partial = d.gnp; g1.gamma = W(c, r.gn1_g.off); g1.beta = W(c, r.gn1_b.off); g1.mask = mask; g1.nrows = d.nr(lvl);
     if (d.folded) { g1.nextra = d.ne(lvl); g1.bias_stats = W(c, r.gn1_bs.off); }
-    g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = 2 * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
+    g1.chbias = tbias; g1.out16 = d.H16; g1.ld16 = d.ew * C; g1.B = B; g1.T = T; g1.C = C;      // already masked
     RET_IF(run_gn_apply(c, g1, s));
     GemmArgs b;
     panel_args(c, r.conv2, b); rows_plain(b, B, T); taps_centered(b, 3);
-    b.a16_0 = d.H16; b.lda16_0 = 2 * C; b.c0 = C; b.out = d.Y; b.ldc = C;
+    b.a16_0 = d.H16; b.lda16_0 = d.ew * C; b.c0 = C; b.out = d.Y; b.ldc = C;
     const int fr2 = gn_fuse_rows(b, C, 8, T);
     if (fr2) { b.gn_stats = d.gns; b.gn_groups = 8; b.gn_nrows = d.nr(lvl); }
     RET_IF(run_gemm(c, b, s));
     if (!fr2) LAUNCH(c, 2, 0, s, launch_gn_partial(d.Y, B, T, C, 8, d.gnp, s, d.nr(lvl)));
     GemmArgs rc;
     panel_args(c, r.res, rc); rows_plain(rc, B, T);
-    rc.a16_0 = in0; rc.lda16_0 = 2 * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = 2 * c1; rc.c1 = c1;
+    rc.a16_0 = in0; rc.lda16_0 = d.ew * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = d.ew * c1; rc.c1 = c1;
     (void)out;                                                        // no fp32 copy: x lives on as its image only
     static const bool tail_on = [] { const char* e = getenv("MTTS_GN_TAIL"); return !(e && e[0] == '0'); }();   // A/B runs
     if (tail_on && fr2 && (T % (2 * gemm_p16_wave_rows(rc))) == 0) {
@@ -803,7 +821,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
         rc.gnr_y = d.Y; rc.gnr_stats = d.gns; rc.gnr_tile_rows = fr2; rc.gnr_groups = 8;
         rc.gnr_gamma = W(c, r.gn2_g.off); rc.gnr_beta = W(c, r.gn2_b.off); rc.gnr_mask = mask;
         if (d.folded) { rc.gnr_nextra = d.ne(lvl); rc.gnr_bias_stats = W(c, r.gn2_bs.off); }
-        rc.out16 = d.X16; rc.ld16 = 2 * C; rc.stats_out = d.lnp;
+        rc.out16 = d.X16; rc.ld16 = d.ew * C; rc.stats_out = d.lnp;
         RET_IF(run_gemm(c, rc, s));
         return 0;
     }
@@ -814,7 +832,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     g2.y = d.Y; g2.partial = d.gnp; g2.gamma = W(c, r.gn2_g.off); g2.beta = W(c, r.gn2_b.off); g2.mask = mask; g2.nrows = d.nr(lvl);
     if (d.folded) { g2.nextra = d.ne(lvl); g2.bias_stats = W(c, r.gn2_bs.off); }
     g2.res = d.Rr; g2.ldr = C; g2.B = B; g2.T = T; g2.C = C;
-    g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = 2 * C;          // unmasked: the first transformer block's LayerNorm input
+    g2.stats_out = d.lnp; g2.out16 = d.X16; g2.ld16 = d.ew * C;          // unmasked: the first transformer block's LayerNorm input
     RET_IF(run_gn_apply(c, g2, s));
     return 0;
 }
@@ -826,7 +844,7 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     const float* tb = d.TB + (size_t)ev * D.tb_total;
     size_t ri = 0, ti = 0;
     // masked x | mu | zero padding as a P16 image (reference decoder.py:379: the first ResNet sees x * mask)
-    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, 2 * d.ldx, 2048.0f, s, c->cur_flag));
+    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, d.ew * d.ldx, 2048.0f, s, c->cur_flag, d.ew == 1));
     const _Float16* cur = d.XM16;
     int cur_c = d.ldx;
     // ---- down path
@@ -839,12 +857,12 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
         GemmArgs a;
         panel_args(c, D.down[l], a);
         taps_centered(a, 3);
-        a.a16_0 = d.S16[l]; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+        a.a16_0 = d.S16[l]; a.lda16_0 = d.ew * r.cout; a.c0 = r.cout;
         a.B = B; a.T_in = d.Tl[l];
         const int lo = l < nl - 1 ? l + 1 : l;
         if (l < nl - 1) { a.T_out = d.Tl[l + 1]; a.in_stride = 2; a.out_T = d.Tl[l + 1]; }   // Downsample1D (reference decoder.py:66-72)
         else { a.T_out = d.Tl[l]; a.out_T = d.Tl[l]; }                                          // last level: Conv1d(k3, p1)
-        a.out16 = d.A16[lo]; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[lo];
+        a.out16 = d.A16[lo]; a.ld16 = d.ew * r.cout; a.out16_mask = d.mask[lo];
         RET_IF(run_gemm(c, a, s));
         cur = d.A16[lo]; cur_c = r.cout;
     }
@@ -873,11 +891,11 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
             for (int ph = 0; ph < 2; ++ph) {
                 GemmArgs a;
                 panel_args(c, ph == 0 ? D.up_even[i] : D.up_odd[i], a);
-                a.a16_0 = dst16; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+                a.a16_0 = dst16; a.lda16_0 = d.ew * r.cout; a.c0 = r.cout;
                 a.B = B; a.T_in = d.Tl[l]; a.T_out = d.Tl[l]; a.in_stride = 1;
                 a.tap_off[0] = ph == 0 ? 0 : 1;
                 a.tap_off[1] = ph == 0 ? -1 : 0;
-                a.out16 = up16; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[l - 1];
+                a.out16 = up16; a.ld16 = d.ew * r.cout; a.out16_mask = d.mask[l - 1];
                 a.out_T = d.Tl[l - 1]; a.out_stride = 2; a.out_off = ph;
                 RET_IF(run_gemm(c, a, s));
             }
@@ -885,9 +903,9 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
         } else {
             GemmArgs a;
             panel_args(c, D.up_last, a); rows_plain(a, B, d.Tl[l]); taps_centered(a, 3);
-            a.a16_0 = dst16; a.lda16_0 = 2 * r.cout; a.c0 = r.cout;
+            a.a16_0 = dst16; a.lda16_0 = d.ew * r.cout; a.c0 = r.cout;
             _Float16* o16 = (dst16 == d.A16[l]) ? d.B16[l] : d.A16[l];
-            a.out16 = o16; a.ld16 = 2 * r.cout; a.out16_mask = d.mask[l];
+            a.out16 = o16; a.ld16 = d.ew * r.cout; a.out16_mask = d.mask[l];
             RET_IF(run_gemm(c, a, s));
             cur = o16;
         }
@@ -897,7 +915,7 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     const int C0 = g.dec_channels[0], T = d.T;
     GemmArgs a;
     panel_args(c, D.final_conv, a); rows_plain(a, B, T); taps_centered(a, 3);
-    a.a16_0 = cur; a.lda16_0 = 2 * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
+    a.a16_0 = cur; a.lda16_0 = d.ew * C0; a.c0 = C0; a.out = d.Y; a.ldc = C0;
     const int frf = gn_fuse_rows(a, C0, 8, T);
     if (frf) { a.gn_stats = d.gns; a.gn_groups = 8; a.gn_nrows = d.nr(0); }
     RET_IF(run_gemm(c, a, s));
@@ -906,11 +924,11 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     if (frf) { ga.tile_stats = d.gns; ga.tile_rows = frf; }
     ga.y = d.Y; ga.partial = d.gnp; ga.gamma = W(c, D.fgn_g.off); ga.beta = W(c, D.fgn_b.off); ga.mask = d.mask[0]; ga.nrows = d.nr(0);
     if (d.folded) { ga.nextra = d.ne(0); ga.bias_stats = W(c, D.fgn_bs.off); }
-    ga.out16 = d.H16; ga.ld16 = 2 * C0; ga.B = B; ga.T = T; ga.C = C0;
+    ga.out16 = d.H16; ga.ld16 = d.ew * C0; ga.B = B; ga.T = T; ga.C = C0;
     RET_IF(run_gn_apply(c, ga, s));
     GemmArgs p;
     panel_args(c, D.final_proj, p); rows_plain(p, B, T);
-    p.a16_0 = d.H16; p.lda16_0 = 2 * C0; p.c0 = C0; p.out_mask = d.mask[0];
+    p.a16_0 = d.H16; p.lda16_0 = d.ew * C0; p.c0 = C0; p.out_mask = d.mask[0];
     p.out = fo.out; p.ldc = fo.ldc; p.res = fo.res; p.ldr = fo.ldr; p.out_scale = fo.scale;
     RET_IF(run_gemm(c, p, s));
     return 0;
@@ -970,16 +988,20 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     mtts_ctx* c = new mtts_ctx();
     c->cfg = g;
     c->gemm_terms = default_gemm_terms();
-    { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; }     // 1 = fp16 mode on the P16 kernels (images as for 2)
+    { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; c->half16 = e && atoi(e) == 16; }   // 1 / 16: fp16 modes (include/mtts.h)
     { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
     return c;
 }
 
 int mtts_set_arithmetic(mtts_ctx* c, int terms) {
     if (!c) { set_error("null context"); return -1; }
-    if (terms != 0 && terms != 1 && terms != 2 && terms != 3 && terms != 6) { set_error("mtts_set_arithmetic: terms must be 0, 1, 2, 3 or 6"); return -1; }
+    if (terms != 0 && terms != 1 && terms != 2 && terms != 3 && terms != 6 && terms != 16) {
+        set_error("mtts_set_arithmetic: terms must be 0, 1, 2, 3, 6 or 16");
+        return -1;
+    }
     c->fast16 = terms == 1;
-    c->gemm_terms = terms == 1 ? 2 : terms;
+    c->half16 = terms == 16;
+    c->gemm_terms = (terms == 1 || terms == 16) ? 2 : terms;
     c->packed = false;
     c->uploaded = false;
     return 0;
@@ -1466,7 +1488,7 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
 }
 
 // ------------------------------------------------------------------------------------------------ measurement
-int mtts_gemm_terms(mtts_ctx* c) { return c ? (c->fast16 ? 1 : c->gemm_terms) : default_gemm_terms(); }
+int mtts_gemm_terms(mtts_ctx* c) { return c ? (c->half16 ? 16 : c->fast16 ? 1 : c->gemm_terms) : default_gemm_terms(); }
 
 int mtts_prof_enable(mtts_ctx* c, int on) {
     if (!c) { set_error("null context"); return -1; }

@@ -342,9 +342,13 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
                     hh[e] = (_Float16)fminf(fmaxf(w, -65504.f), 65504.f);
                     ll[e] = (_Float16)fminf(fmaxf((w - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
                 }
-                _Float16* o16 = p.out16 + row[u] * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
-                *reinterpret_cast<f16x4*>(o16) = hh;
-                *reinterpret_cast<f16x4*>(o16 + 32) = ll;
+                if (p.half16) {
+                    *reinterpret_cast<f16x4*>(p.out16 + row[u] * (size_t)p.ld16 + c4 * 4) = hh;
+                } else {
+                    _Float16* o16 = p.out16 + row[u] * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;
+                    *reinterpret_cast<f16x4*>(o16) = hh;
+                    *reinterpret_cast<f16x4*>(o16 + 32) = ll;
+                }
             }
             if (p.stats_out) {   // LayerNorm partial moments of the row's 64-column slices (16 threads = one DPP row each), as
                                  // the GEMM epilogue leaves them: the first transformer block needs no row_stats pass
@@ -368,7 +372,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
-    if (a.out16 && ((a.C & 31) || a.ld16 < 2 * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
+    if (a.out16 && ((a.C & 31) || a.ld16 < (a.half16 ? 1 : 2) * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.tile_stats && (a.tile_rows <= 0 || (a.T % a.tile_rows) || (a.C & 63) || (a.C / a.G) < 32)) return hipErrorInvalidValue;
     if ((a.nextra != nullptr) != (a.bias_stats != nullptr)) return hipErrorInvalidValue;
     GnApplyArgs b = a;
