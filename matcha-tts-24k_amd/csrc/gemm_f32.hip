@@ -492,8 +492,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ weight packing
 void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT, const int* tsel, const float* col_scale,
-                      float* dst) {
-    const int ktap = round_up(C, GEMM_BK);
+                      float* dst, int ktap) {
+    if (ktap <= 0) ktap = round_up(C, GEMM_BK);
     const int Kp = ntaps * ktap;
     const int Np = round_up(N, GEMM_BN);
     for (size_t i = 0; i < (size_t)Np * Kp; ++i) dst[i] = 0.f;

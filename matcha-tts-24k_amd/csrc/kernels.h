@@ -118,7 +118,7 @@ static inline double gemm_bytes(const GemmArgs& a) {
 // Pack a torch weight into the GEMM panel layout [Np][ntaps*ktap] (host side).
 //   kind 0: Linear [N, C]   kind 1: Conv1d [N, C, ntaps]   kind 2: ConvTranspose1d [C, N, kT] taking taps `tsel[0..ntaps)`
 void pack_weight_host(const float* w, int kind, int N, int C, int ntaps, int kT, const int* tsel, const float* col_scale,
-                      float* dst);
+                      float* dst, int ktap = 0);      // ktap: padded K per tap (0 = round_up(C, 32))
 // Device-side packing of an unpacked Linear/Conv1d weight (used by the single-kernel test entry point).
 hipError_t launch_pack_weight(const float* w, int N, int C, int ntaps, float* dst, hipStream_t s);
 void split_panel_host(const float* panel, size_t n, uint16_t* planes);

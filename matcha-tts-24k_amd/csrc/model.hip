@@ -103,6 +103,8 @@ struct Packer {
     mtts_ctx* c;
     bool ok = true;
     std::string why;
+    int kq = GEMM_BK;          // K padding per tap of the panels being packed: 64 for the estimator in the 16-bit storage mode
+    bool h16 = false;          // ... which also get the single fp16 plane (Panel::wh16)
     explicit Packer(mtts_ctx* ctx) : c(ctx) {}
     const std::vector<float>* get(const std::string& key, size_t numel) {
         auto it = c->raw.find(key);
@@ -164,7 +166,7 @@ struct Packer {
             const int Np = round_up(p.N, GEMM_BN);
             const size_t Kp = (size_t)p.ntaps * p.ktap;
             p.wsum = alloc(Np);
-            if (c->half16) {      // 16-bit storage mode: the fp16 head plane alone + row sums of the ROUNDED weights (LN epilogue)
+            if (h16) {            // 16-bit storage mode: the fp16 head plane alone + row sums of the ROUNDED weights (LN epilogue)
                 p.wh16 = alloc((n + 1) / 2);
                 panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
             }
@@ -172,7 +174,7 @@ struct Packer {
                 double acc = 0.0;
                 for (size_t k = 0; k < Kp; ++k) {
                     const float w = c->image[p.w + (size_t)r * Kp + k];
-                    acc += c->half16 ? (double)(float)(_Float16)fminf(fmaxf(w, -65504.f), 65504.f) : (double)w;
+                    acc += h16 ? (double)(float)(_Float16)fminf(fmaxf(w, -65504.f), 65504.f) : (double)w;
                 }
                 c->image[p.wsum + r] = (float)acc;
             }
@@ -181,12 +183,12 @@ struct Packer {
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
         Panel p;
-        p.N = N; p.C = C; p.ntaps = ntaps; p.ktap = round_up(C, c->half16 ? 64 : GEMM_BK);
+        p.N = N; p.C = C; p.ntaps = ntaps; p.ktap = round_up(C, kq);
         const int Np = round_up(N, GEMM_BN);
         const size_t Kp = (size_t)ntaps * p.ktap;
         p.w = alloc((size_t)Np * Kp);
         p.b = alloc(Np);
-        pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w]);
+        pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w], p.ktap);
         if (bias) { p.has_bias = true; std::memcpy(&c->image[p.b], bias, N * sizeof(float)); }
         add_planes(p);
         return p;
@@ -200,7 +202,7 @@ struct Packer {
         p.N = N_each * parts;
         p.C = C;
         p.ntaps = ntaps;
-        p.ktap = round_up(C, c->half16 ? 64 : GEMM_BK);
+        p.ktap = round_up(C, kq);
         const int Np = round_up(p.N, GEMM_BN);
         const size_t Kp = (size_t)ntaps * p.ktap;
         p.w = alloc((size_t)Np * Kp);
@@ -210,7 +212,7 @@ struct Packer {
         for (int part = 0; part < parts; ++part) {
             const auto* w = get(wkeys[part], per);
             if (!w) return p;
-            pack_weight_host(w->data(), kind, N_each, C, ntaps, kT, tsel, col_scale ? col_scale->data() : nullptr, tmp.data());
+            pack_weight_host(w->data(), kind, N_each, C, ntaps, kT, tsel, col_scale ? col_scale->data() : nullptr, tmp.data(), p.ktap);
             std::memcpy(&c->image[p.w + (size_t)part * N_each * Kp], tmp.data(), (size_t)N_each * Kp * sizeof(float));
             const bool hb = part < (int)bkeys.size() && !bkeys[part].empty();
             const std::vector<float>* b = hb ? get(bkeys[part], N_each) : nullptr;
@@ -285,6 +287,8 @@ static int pack_all(mtts_ctx* c) {
     E.dp_proj = P.panel("encoder.proj_w.proj.weight", "encoder.proj_w.proj.bias", 1, 1, F, 1);
 
     // ---------------- decoder (reference decoder.py:202-310)
+    P.kq = c->half16 ? 64 : GEMM_BK;
+    P.h16 = c->half16;
     DecW& D = c->dec;
     D = DecW();
     const std::string R = "decoder.estimator.";
@@ -370,7 +374,7 @@ static int pack_all(mtts_ctx* c) {
         for (size_t i = 0; i < D.res.size(); ++i) { D.res[i].tb_off = total; total += mlp_n[i]; }
         D.tb_total = total;
         Panel p;
-        p.N = total; p.C = temb; p.ntaps = 1; p.ktap = round_up(temb, c->half16 ? 64 : GEMM_BK); p.has_bias = true;
+        p.N = total; p.C = temb; p.ntaps = 1; p.ktap = round_up(temb, P.kq); p.has_bias = true;
         p.w = P.alloc((size_t)round_up(total, GEMM_BN) * p.ktap);
         p.b = P.alloc(round_up(total, GEMM_BN));
         for (size_t i = 0; i < D.res.size() && P.ok; ++i) {
@@ -408,7 +412,7 @@ static void panel_args(const mtts_ctx* c, const Panel& p, GemmArgs& a) {
     a.bias = p.has_bias ? W(c, p.b) : nullptr;
     a.wsum = c->gemm_terms == 2 ? W(c, p.wsum) : nullptr;
     a.fast16 = c->fast16;
-    a.w16h = c->half16 ? static_cast<const void*>(W(c, p.wh16)) : nullptr;
+    a.w16h = (c->half16 && p.wh16) ? static_cast<const void*>(W(c, p.wh16)) : nullptr;
     a.N = p.N;
     a.ntaps = p.ntaps;
     a.ktap = p.ktap;
