@@ -311,6 +311,16 @@ class HipModel:
             check(-1)
         return bool(r)
 
+    def decoder_workspace_bytes(self, B: int, T: int) -> int:
+        n = self.lib.mtts_decoder_workspace_bytes(self.ctx, int(B), int(T))
+        if n < 0:
+            check(-1)
+        return n
+
+    def note_workspace(self, kind: str, ws: torch.Tensor) -> None:
+        """Make ``ws`` the buffer ``range_flags`` reads for this stream (a replayed HIP graph ran on it)."""
+        self._last_ws[(kind, stream_ptr())] = ws
+
     def workspace_bytes_held(self) -> int:
         return sum(int(w.numel()) for w in self._ws.values())
 
@@ -400,9 +410,10 @@ class HipModel:
 
     def cfm_solve(self, x0, mu, mask, t_span, solver: str, add_mu: bool = False, t_out: Optional[int] = None,
                   out_scale: float = 1.0, out_shift: float = 0.0, y_lengths=None, y_max: Optional[int] = None,
-                  t_fold: Optional[int] = None):
+                  t_fold: Optional[int] = None, ws: Optional[torch.Tensor] = None):
         """``y_lengths`` (int64 [B] on the device) + ``y_max`` + ``t_fold``: prefix masks on folded padding
-        (mtts_cfm_solve_folded; ``mask`` is then not read)."""
+        (mtts_cfm_solve_folded; ``mask`` is then not read).  ``ws``: caller-owned scratch (HIP-graph capture: the buffer must
+        belong to the graph, not to the per-stream cache)."""
         x0, mu = self._f32(x0), self._f32(mu)
         B, nf, T = x0.shape
         if solver not in SOLVERS:
@@ -412,7 +423,10 @@ class HipModel:
         out = torch.empty(B, nf, t_out, dtype=torch.float32, device=x0.device)
         if t_fold is not None:
             y_lengths = y_lengths.detach().to(torch.int64).contiguous()
-            ws = self._workspace("dec", B, int(t_fold))
+            if ws is None:
+                ws = self._workspace("dec", B, int(t_fold))
+            else:
+                self._last_ws[("dec", stream_ptr())] = ws
             check(self.lib.mtts_cfm_solve_folded(self.ctx, ptr(x0), ptr(mu), ptr(y_lengths), int(y_max), int(bool(add_mu)),
                                                  ts.ctypes.data, len(ts) - 1, SOLVERS[solver], B, T, int(t_fold), ptr(out), t_out,
                                                  float(out_scale), float(out_shift), ws.data_ptr(), ws.numel(), stream_ptr()))

@@ -7,6 +7,7 @@ the HIP library through one shared ``HipModel``.  There is no PyTorch arithmetic
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import Optional
 
@@ -117,6 +118,14 @@ class CFM(nn.Module):
         self.use_mu_prior = hp.use_mu_prior
         self.fold_padding = os.environ.get("MTTS_FOLD", "1") != "0"
         self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "8"))
+        # HIP graphs for launch-bound sizes (SURVEY section 7 "launch-bound small batches"): "auto" = when the estimator holds
+        # at most graph_max_rows rows (B * rows per utterance), "1" always, "0" never
+        self.graph_mode = os.environ.get("MTTS_GRAPH", "auto")
+        self.graph_max_rows = int(os.environ.get("MTTS_GRAPH_MAX_ROWS", "6144"))
+        self.graph_bucket = 64
+        object.__setattr__(self, "_graphs", collections.OrderedDict())
+        self.graph_cache_entries = int(os.environ.get("MTTS_GRAPH_CACHE", "24"))
+        self.graph_replays = 0
         object.__setattr__(self, "_rt", rt)
         self.estimator = Estimator()
         self.estimator._bind(rt)
@@ -163,6 +172,8 @@ class CFM(nn.Module):
             z = self.noise(mu) if t_len is None else self.noise_per_request(mu, t_len)
         t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
         kw = dict(add_mu=self.use_mu_prior, t_out=t_out, out_scale=out_scale, out_shift=out_shift)
+        if y_lengths is not None and y_max is not None and self._graph_wanted(mu.shape[0], y_max):
+            return self._solve_on_graph(hip, mu, z, n_timesteps, t_out, out_scale, out_shift, t_len, y_lengths, y_max)
         t_fold = self.fold_plan(mu.shape[-1], y_max) if y_lengths is not None else None
         if t_fold is not None and (t_out is None or t_out <= t_fold):
             kw.update(y_lengths=y_lengths, y_max=y_max, t_fold=t_fold)
@@ -173,6 +184,66 @@ class CFM(nn.Module):
             return hip.cfm_solve(z, mu, mask, t_span, self.solver, **kw)
         finally:
             hip.set_frame_limits(None)
+
+    # ------------------------------------------------------------------ HIP graphs
+    def _graph_rows(self, y_max: int) -> int:
+        """Rows per utterance of the graph that serves valid lengths up to y_max: the folded row count, rounded up to a bucket
+        so that requests of similar length replay the same graph.  Filler rows change nothing (include/mtts.h
+        mtts_cfm_solve_folded): the reference's padded length reaches the kernels as DATA (mtts_set_frame_limits), not as a shape."""
+        rows = self._rt.ready().fold_rows(y_max, self.fold_align)
+        return (rows + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket
+
+    def _graph_wanted(self, B: int, y_max: int) -> bool:
+        if self.graph_mode == "0" or not self.fold_padding:
+            return False
+        return self.graph_mode == "1" or B * self._graph_rows(y_max) <= self.graph_max_rows
+
+    def _solve_on_graph(self, hip, mu, z, n_timesteps, t_out, out_scale, out_shift, t_len, y_lengths, y_max):
+        """One ODE solve as ONE graph launch: the ~100 kernels per evaluation are captured once per (batch, row bucket, solver,
+        steps) with static input / scratch / output buffers and replayed; per call only the inputs are copied in."""
+        B, nf, T = mu.shape
+        rows = self._graph_rows(y_max)
+        f = 2 ** (len(self._rt.hp.decoder.channels) - 1)
+        y_cap = (rows // f - 1) * f                       # the longest valid length these rows can hold
+        t_src = 2 * rows                                  # source row stride: >= any T_pad whose valid length fits
+        key = (B, rows, self.solver, int(n_timesteps), float(out_scale), float(out_shift), bool(self.use_mu_prior), hip.gemm_terms())
+        e = self._graphs.get(key)
+        if e is None:
+            dev = mu.device
+            e = {"z": torch.zeros(B, nf, t_src, device=dev), "mu": torch.zeros(B, nf, t_src, device=dev),
+                 "ylen": torch.ones(B, dtype=torch.int64, device=dev), "tlen": torch.full((B,), 2, dtype=torch.int32, device=dev),
+                 "ws": torch.empty(hip.decoder_workspace_bytes(B, rows), dtype=torch.uint8, device=dev)}
+            t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
+            kw = dict(add_mu=self.use_mu_prior, t_out=rows, out_scale=out_scale, out_shift=out_shift, y_lengths=e["ylen"],
+                      y_max=y_cap, t_fold=rows, ws=e["ws"])
+            hip.set_frame_limits(e["tlen"])
+            try:
+                hip.cfm_solve(e["z"], e["mu"], None, t_span, self.solver, **kw)      # warm-up: lazy kernel attributes are set here
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    e["out"] = hip.cfm_solve(e["z"], e["mu"], None, t_span, self.solver, **kw)
+                e["graph"] = g
+            finally:
+                hip.set_frame_limits(None)
+            self._graphs[key] = e
+            while len(self._graphs) > self.graph_cache_entries:
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        w = min(T, rows)
+        e["z"][:, :, :w].copy_(z[:, :, :w])
+        e["mu"][:, :, :w].copy_(mu[:, :, :w])
+        e["ylen"].copy_(y_lengths)
+        if t_len is None:
+            e["tlen"].fill_(T)                              # the reference's batch-wide padded length
+        else:
+            e["tlen"].copy_(torch.as_tensor(list(t_len), dtype=torch.int32))
+        e["graph"].replay()
+        hip.note_workspace("dec", e["ws"])
+        self.graph_replays += 1
+        n_out = rows if t_out is None else int(t_out)
+        return e["out"][:, :, :n_out].clone()
 
     def solve(self, x, t_span, mu, mask):
         return self._rt.ready().cfm_solve(x, mu, mask, t_span, self.solver)

@@ -439,6 +439,42 @@ def test_per_request_padding_on_folded_rows(tiny, prod, synthetic, dev):
         assert maxabs(folded["mel"], full["mel"]) < 1e-4
 
 
+# ------------------------------------------------------------------------------------------------ HIP graphs (small batches)
+def test_graph_replay_equals_direct_launches(prod, tiny, synthetic, dev):
+    """Launch-bound sizes run the ODE solve as one captured HIP graph per (batch, row bucket, solver, steps) (modules.CFM.
+    _solve_on_graph): static buffers, the reference's padded length as device data.  Results equal the direct launches (only
+    the bucketed row count, hence tile shapes, may differ: rounding level); requests whose lengths share a bucket replay the
+    same graph; per-request padding and the reference's batch-wide padding both ride on it."""
+    for (hp, sd, model), cases in ((prod, [([40], "euler", 3), ([47], "euler", 3), ([33, 47], "midpoint", 2), ([47, 20], "midpoint", 2)]),
+                                   (tiny, [([12, 9, 5], "euler", 2), ([11, 12, 3], "euler", 2)])):
+        dec = model.decoder
+        keep = dec.graph_mode
+        try:
+            dec._graphs.clear()
+            n_graphs = 0
+            for lengths, solver, steps in cases:
+                B = len(lengths)
+                x, x_len, spk = synthetic.make_inputs(hp, B, max(lengths), seed=61, lengths=lengths)
+                spk = spk % hp.n_spks
+                dec.solver = solver
+                for prp in (False, True):
+                    dec.graph_mode = "0"
+                    direct = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev), per_request_padding=prp)
+                    dec.graph_mode = "1"
+                    before = dec.graph_replays
+                    graphed = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev), per_request_padding=prp)
+                    assert dec.graph_replays == before + 1
+                    assert torch.equal(graphed["mel_lengths"], direct["mel_lengths"])
+                    assert graphed["mel"].shape == direct["mel"].shape
+                    assert maxabs(graphed["mel"], direct["mel"]) < 5e-5, (lengths, solver, prp)
+                    again = model.synthesise(x.to(dev), x_len.to(dev), steps, speaker=spk.to(dev), per_request_padding=prp)
+                    assert torch.equal(again["mel"], graphed["mel"])
+            # lengths 40 and 47 (and the two ragged pairs) share row buckets: fewer graphs than cases
+            assert len(dec._graphs) < len(cases), (len(dec._graphs), len(cases))
+        finally:
+            dec.graph_mode = keep
+
+
 # ------------------------------------------------------------------------------------------------ 16-bit storage mode (config #3)
 def _half_model(hp, sd, dev, monkeypatch):
     monkeypatch.setenv("MTTS_GEMM_TERMS", "16")
