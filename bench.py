@@ -182,6 +182,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:      # unreachable from the command line (_self_launch_if_needed), kept for importers
         raise SystemExit("--gpus N>1 needs one rank per GPU: run `python bench.py --gpus N` or launch under torch.distributed.run")
+    if os.environ.get("MTTS_BENCH_DRYRUN") == "1":
+        # launch rehearsal without a device (tests/test_bench_launch.py): the ranks rendezvous over gloo, agree on a value and
+        # rank 0 prints one line; no part of the product path runs
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            got = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            got = 0
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "max_rank": got, "gpus_arg": args.gpus}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     # MTTS_DIST_BACKEND=gloo: rehearsal of the N-rank job on fewer cards (ranks share devices, collectives staged through host

@@ -46,14 +46,10 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // ONE: the opt-in fp16 mode (MTTS_GEMM_TERMS=1): only the head planes are multiplied (one MFMA per 16-deep block instead of
 // three, half the fragment reads) -- fp16 operand precision with fp32 accumulation, what torch.autocast gives the reference.
 // M16: v_mfma_f32_16x16x32_f16 tiles (MT x 4 per wave) instead of 32x32x16 (MI x 2).
-// PIPE (M16 tiles only): register double-buffering of the operand fragments.  The fragments of tile kt+1 are read from LDS
-// while the MFMAs of tile kt run on the registers loaded one iteration earlier, so a k-step costs max(MFMA time, LDS + DMA
-// issue) instead of their sum; tile kt's stage is free as soon as the step begins and takes the DMA of tile kt+NST (NST tiles
-// ahead with NST stages).  Costs a second fragment set in registers (BM = 64: 48 VGPRs).
 // MODE: 0 = P16 operands, three products per MAC (the default, fp32-equivalent); 1 = P16 operands, heads x heads only (the
 // opt-in fp16 mode, ONE); 2 = H16 operands (GemmArgs::half16): a 128-byte line holds 64 k of one fp16 plane, a k-step is 64
 // deep and its two 32-k halves are what the head / residual chunks of a P16 line are to the DMA and the fragment reads.
-template <int BM, bool LN, int NST, int MODE, bool M16, bool PIPE = false>
+template <int BM, bool LN, int NST, int MODE, bool M16>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     constexpr bool ONE = MODE == 1;
     constexpr bool HALF = MODE == 2;
@@ -192,36 +188,6 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
     };
-    struct Frags { f16x8 ah[MT], al[MT], bh[4], bl[4]; };
-    auto load_frags = [&](const char* stage, Frags& f) {
-        const char* sa = stage + (wm * (BM / 2) + fr) * 128;
-        const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
-        const int sh = (fq ^ f8) * 16, sl = ((4 + fq) ^ f8) * 16;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            f.ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sh);
-            if constexpr (!ONE) f.al[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sl);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f.bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sh);
-            if constexpr (!ONE) f.bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sl);
-        }
-    };
-    auto mma_frags = [&](const Frags& f) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (HALF) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
-                } else if constexpr (!ONE) {
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bh[j], accx[i][j], 0, 0, 0);
-                }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-            }
-    };
     auto compute32 = [&](const char* stage) {
         const char* sa = stage + (wm * (BM / 2) + fr32) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr32) * 128;
@@ -335,39 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         }
     };
     setup_run();
-    if constexpr (PIPE) {
-        static_assert(M16 && (NST == 2 || NST == 3), "PIPE: 16x16x32 tiles, 2 or 3 stages");
-        constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
-        for (int t = 0; t < NST && t < nk; ++t) issue(t);
-        ln_stats();
-        gnr_prologue();
-        // tile 0 has landed once at most the NST-1 younger tiles are outstanding
-        if (nk >= NST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 1) * PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        Frags f0, f1;
-        load_frags(lds, f0);
-        int st = 0;                            // stage of tile kt
-        auto step = [&](int kt, Frags& cur, Frags& nxt) {
-            const int st1 = st + 1 == NST ? 0 : st + 1;
-            if (kt + 1 < nk) {
-                // tile kt+1 landed for this wave (the NST-2 younger ones may still fly); lgkmcnt(0): this wave's reads of tile
-                // kt are in `cur`; after the barrier both hold for every wave, so stage st may be refilled
-                if (NST == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (kt + NST < nk) issue(st);
-                load_frags(lds + st1 * STAGE, nxt);
-            }
-            mma_frags(cur);
-            st = st1;
-        };
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            step(kt, f0, f1);
-            step(kt + 1, f1, f0);
-        }
-        if (kt < nk) step(kt, f0, f1);
-        __syncthreads();                       // the epilogue tile overlays the stages: everyone is done reading
-    } else if constexpr (NST == 2) {
+    if constexpr (NST == 2) {
         issue(0);
         ln_stats();
         gnr_prologue();
@@ -425,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
 // at most one workgroup per CU are latency-bound and lose 4 % with the longer 16x16 issue sequence; B <= 8 serving shapes).
-template <int BM, bool LN, int NST, int MODE, bool M16, bool PIPE = false>
+template <int BM, bool LN, int NST, int MODE, bool M16>
 static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16, PIPE>;
+    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16>;
     constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -444,16 +378,7 @@ static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
 template <int BM, bool LN, int NST, int MODE>
 static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     // MFMA shape by pipeline depth: 16x16x32 wherever a CU holds more than one workgroup, 32x32x16 on the 4-stage ring (see above)
-    if constexpr (NST == 4) return launch_p16_shape<BM, LN, NST, MODE, false>(a, s);
-#ifdef MTTS_BUILD_PIPE_VARIANT
-    else if constexpr (BM == 64 && MODE == 0) {
-        // 64-row tiles: MTTS_P16_PIPE=1 double-buffers the operand fragments in registers (PIPE).  Not built by default: measured
-        // 31.2 vs 30.5 ms/step at B = 32 (r02) -- the loop is bound by operand delivery (LDS-DMA issue), not by the fragment reads
-        static const bool pipe = [] { const char* e = getenv("MTTS_P16_PIPE"); return e && e[0] == '1'; }();
-        return pipe ? launch_p16_shape<BM, LN, NST, MODE, true, true>(a, s) : launch_p16_shape<BM, LN, NST, MODE, true>(a, s);
-    }
-#endif
-    else return launch_p16_shape<BM, LN, NST, MODE, true>(a, s);
+    return launch_p16_shape<BM, LN, NST, MODE, NST != 4>(a, s);
 }
 
 template <int BM, bool LN, int NST = 2>
