@@ -54,7 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     global BUILD_MODE
     srcs = [CSRC / s for s in SOURCES]
     if LIB.exists() and not force:
-        newest = max(p.stat().st_mtime for p in srcs + HEADERS)
+        deps = set(HEADERS)
+        for src in srcs:
+            deps |= _deps(src.resolve())
+        newest = max(p.stat().st_mtime for p in deps)
         if LIB.stat().st_mtime >= newest:
             BUILD_MODE = f"reused {LIB.name} (newer than every source and header)"
             return LIB

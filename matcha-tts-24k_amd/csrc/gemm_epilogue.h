@@ -27,7 +27,8 @@ __device__ __forceinline__ float allreduce64(float v) {     // every lane gets t
 }
 
 // LN: LayerNorm-in-the-epilogue (P16 kernel): srow = [BM means | BM rstds] in LDS, p.wsum = panel row sums.
-template <int BM, bool LN>
+// GN: the GroupNorm-statistics part is compiled in (conv GEMMs feeding a Block1D); every other instantiation stays lean.
+template <int BM, bool LN, bool GN = false>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
                                                    int M, int m0, int n0, int wm, int wn, int lane, const float* __restrict__ gstat = nullptr) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -44,41 +45,62 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
     }
     // ---- GroupNorm statistics of the output (conv feeding a Block1D): two passes over the parked tile -- the group means of
     // this wave tile first, then squared deviations inside the main loop -- so no second trip over the tensor is needed.
-    const bool gn = p.gn_stats != nullptr;
-    int gn_rows = 0, gn_gi = 0;
-    float gn_mean[2] = {0.f, 0.f}, gn_n[2] = {0.f, 0.f}, gn_q = 0.f;
-    if (gn) {
-        const int rows_w = BM / 2, row_w0 = m0 + wm * rows_w;             // T_out % rows_w == 0: one batch element per wave tile
-        const int b = min(row_w0 / p.T_out, p.B - 1), t_w0 = row_w0 - b * p.T_out;      // (tail tiles past M: gn_rows = 0 below)
-        const int Tb = p.gn_nrows ? min(p.T_out, p.gn_nrows[b]) : p.T_out;
-        gn_rows = row_w0 < M ? max(0, min(rows_w, Tb - t_w0)) : 0;
+    // Granule: the wave tile (BM/2 rows x 64 columns), split where it crosses into the next utterance (T_out >= BM/2, so at most
+    // two parts): per part and group slice (<= 2) an entry (n, mean, M2).
+    const bool gn = GN && p.gn_stats != nullptr;
+    int gn_gi = 0, gn_cols0 = 64, gn_bnd = BM, gn_cnt0 = 0, gn_cnt1 = 0;   // part 0 = rows [0, cnt0), part 1 = rows [bnd, bnd + cnt1)
+    float gn_mean[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gn_mu0 = 0.f, gn_mu1 = 0.f, gn_q0 = 0.f, gn_q1 = 0.f;
+    if constexpr (GN) if (gn) {
+        constexpr int rows_w = BM / 2;
+        const int row_w0 = m0 + wm * rows_w;
         const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
-        const int cols0 = min(64, (g0 + 1) * cpg - n0w);
+        gn_cols0 = min(64, (g0 + 1) * cpg - n0w);
         gn_gi = (nc / cpg) - g0;                                          // 0 or 1: this lane's group slice (cpg >= 32)
-        gn_n[0] = (float)(gn_rows * cols0);
-        gn_n[1] = (float)(gn_rows * (64 - cols0));
-        float s1 = 0.f;
+        if (row_w0 < M) {
+            const int b0 = row_w0 / p.T_out, t_w0 = row_w0 - b0 * p.T_out;
+            const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
+            const int nr1 = (b0 + 1 < p.B) ? (p.gn_nrows ? min(p.T_out, p.gn_nrows[b0 + 1]) : p.T_out) : 0;
+            gn_bnd = min(rows_w, p.T_out - t_w0);
+            gn_cnt0 = max(0, min(gn_bnd, nr0 - t_w0));
+            gn_cnt1 = max(0, min(rows_w - gn_bnd, nr1));
+        }
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rl = it * 4 + (lane >> 4);
-            if (rl < gn_rows) {
+            const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
+            if (in0 || in1) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(Cw + rl * GEMM_CS + (lane & 15) * 4) + bias4;
-                s1 += (a[0] + a[1]) + (a[2] + a[3]);
+                const float t = (a[0] + a[1]) + (a[2] + a[3]);
+                if (in0) s0 += t; else s1 += t;
             }
         }
-        const float t0 = allreduce64(gn_gi == 0 ? s1 : 0.f), t1 = allreduce64(gn_gi == 1 ? s1 : 0.f);
-        gn_mean[0] = gn_n[0] > 0.f ? t0 / gn_n[0] : 0.f;
-        gn_mean[1] = gn_n[1] > 0.f ? t1 / gn_n[1] : 0.f;
+        const float c0f = (float)gn_cols0, c1f = (float)(64 - gn_cols0);
+        const float t00 = allreduce64(gn_gi == 0 ? s0 : 0.f), t01 = allreduce64(gn_gi == 1 ? s0 : 0.f);
+        gn_mean[0][0] = gn_cnt0 > 0 ? t00 / ((float)gn_cnt0 * c0f) : 0.f;
+        gn_mean[0][1] = (gn_cnt0 > 0 && gn_cols0 < 64) ? t01 / ((float)gn_cnt0 * c1f) : 0.f;
+        if (gn_cnt1 > 0) {                                                // wave-uniform
+            const float t10 = allreduce64(gn_gi == 0 ? s1 : 0.f), t11 = allreduce64(gn_gi == 1 ? s1 : 0.f);
+            gn_mean[1][0] = t10 / ((float)gn_cnt1 * c0f);
+            gn_mean[1][1] = gn_cols0 < 64 ? t11 / ((float)gn_cnt1 * c1f) : 0.f;
+        }
+        gn_mu0 = gn_gi == 0 ? gn_mean[0][0] : gn_mean[0][1];
+        gn_mu1 = gn_gi == 0 ? gn_mean[1][0] : gn_mean[1][1];
     }
-    const float gn_mu = gn_gi == 0 ? gn_mean[0] : gn_mean[1];
     bool range_bad = false;
     // Block1D tail: this lane's group statistics (merged in the prologue into gstat = [mean x 4 | rstd x 4]) and affine
-    float gnr_mu = 0.f, gnr_rs = 1.f;
+    // (a workgroup's rows may straddle two utterances: gstat = [utterance u: mean x 4 | rstd x 4] for u = 0, 1; rows from
+    // gnr_bnd on belong to the second)
+    float gnr_mu = 0.f, gnr_rs = 1.f, gnr_mu1 = 0.f, gnr_rs1 = 1.f;
+    int gnr_bnd = 0x7fffffff;
     f32x4 gnr_gm = {0.f, 0.f, 0.f, 0.f}, gnr_bt = gnr_gm;
     if (p.gnr_y && col_ok) {
         const int cpg = p.N / p.gnr_groups, gl = nc / cpg - n0 / cpg;
         gnr_mu = gstat[gl];
         gnr_rs = gstat[4 + gl];
+        gnr_mu1 = gstat[8 + gl];
+        gnr_rs1 = gstat[12 + gl];
+        gnr_bnd = (m0 / p.T_out + 1) * p.T_out;
         gnr_gm = *reinterpret_cast<const f32x4*>(p.gnr_gamma + nc);
         gnr_bt = *reinterpret_cast<const f32x4*>(p.gnr_beta + nc);
     }
@@ -140,9 +162,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 } else {
                     o = a + bias4;
                 }
-                if (gn && rl < gn_rows) {
-                    const f32x4 d = o - gn_mu;
-                    gn_q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                if (GN && gn) {
+                    const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
+                    if (in0 || in1) {
+                        const f32x4 d = o - (in0 ? gn_mu0 : gn_mu1);
+                        const float t = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                        if (in0) gn_q0 += t; else gn_q1 += t;
+                    }
                 }
                 if constexpr (ACT == 1) {
 #pragma unroll
@@ -155,7 +181,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                 if (p.out_scale != 1.0f) o *= p.out_scale;
                 if constexpr (RESK == 1) o += L.rres[u];
                 if constexpr (RESK == 3) {           // Mish(GroupNorm(y)) * mask, same operation order as gn_apply_kernel
-                    f32x4 v = ((L.rres[u] - gnr_mu) * gnr_rs) * gnr_gm + gnr_bt;
+                    const bool second = L.orow[u] >= gnr_bnd;
+                    f32x4 v = ((L.rres[u] - (second ? gnr_mu1 : gnr_mu)) * (second ? gnr_rs1 : gnr_rs)) * gnr_gm + gnr_bt;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mish_f(v[e]) * L.gmk[u];
                     o += v;
@@ -223,13 +250,19 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         else run(IntC<2>{}, IntC<0>{});
     }
     raise_range_flag(p.range_flag, range_bad);
-    if (gn) {
-        const float q0 = allreduce64(gn_gi == 0 ? gn_q : 0.f), q1 = allreduce64(gn_gi == 1 ? gn_q : 0.f);
-        if (lane == 0 && m0 + wm * (BM / 2) < M) {
-            const int row_wave = (m0 + wm * (BM / 2)) / (BM / 2), col_wave = (n0 + wn * 64) >> 6;
-            float* e = p.gn_stats + ((size_t)(row_wave * (p.N >> 6) + col_wave) * 2) * 4;
-            *reinterpret_cast<f32x4*>(e) = f32x4{gn_n[0], gn_mean[0], q0, 0.f};
-            *reinterpret_cast<f32x4*>(e + 4) = f32x4{gn_n[1], gn_mean[1], q1, 0.f};
+    if constexpr (GN) if (gn) {
+        const int row_w0 = m0 + wm * (BM / 2), col_wave = (n0 + wn * 64) >> 6;
+        const float q00 = allreduce64(gn_gi == 0 ? gn_q0 : 0.f), q01 = allreduce64(gn_gi == 1 ? gn_q0 : 0.f);
+        float q10 = 0.f, q11 = 0.f;
+        if (gn_cnt1 > 0) { q10 = allreduce64(gn_gi == 0 ? gn_q1 : 0.f); q11 = allreduce64(gn_gi == 1 ? gn_q1 : 0.f); }
+        if (lane == 0 && row_w0 < M) {
+            const int tile = row_w0 / (BM / 2);
+            float* e = p.gn_stats + ((size_t)((tile * 2) * (p.N >> 6) + col_wave) * 2) * 4;       // part 0
+            *reinterpret_cast<f32x4*>(e) = f32x4{(float)(gn_cnt0 * gn_cols0), gn_mean[0][0], q00, 0.f};
+            *reinterpret_cast<f32x4*>(e + 4) = f32x4{(float)(gn_cnt0 * (64 - gn_cols0)), gn_mean[0][1], q01, 0.f};
+            float* e1 = e + (size_t)(p.N >> 6) * 8;                                                // part 1
+            *reinterpret_cast<f32x4*>(e1) = f32x4{(float)(gn_cnt1 * gn_cols0), gn_mean[1][0], q10, 0.f};
+            *reinterpret_cast<f32x4*>(e1 + 4) = f32x4{(float)(gn_cnt1 * (64 - gn_cols0)), gn_mean[1][1], q11, 0.f};
         }
     }
 }

@@ -49,8 +49,9 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // MODE: 0 = P16 operands, three products per MAC (the default, fp32-equivalent); 1 = P16 operands, heads x heads only (the
 // opt-in fp16 mode, ONE); 2 = H16 operands (GemmArgs::half16): a 128-byte line holds 64 k of one fp16 plane, a k-step is 64
 // deep and its two 32-k halves are what the head / residual chunks of a P16 line are to the DMA and the fragment reads.
-template <int BM, bool LN, int NST, int MODE, bool M16>
+template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false>
 __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
+    static_assert(!(GN && LN), "GroupNorm statistics come from conv GEMMs, which have no LayerNorm prologue");
     constexpr bool ONE = MODE == 1;
     constexpr bool HALF = MODE == 2;
     constexpr int KSTEP = HALF ? 64 : 32;                  // k elements per 128-byte line
@@ -254,24 +255,39 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     };
     // ---- Block1D tail (gnr_*): wave 0 merges the producing conv's tile entries for the <= 4 groups under this workgroup's 128
     // columns (16 lanes per group, Chan merge, fixed order) into gstat = [mean x 4 | rstd x 4], parked where srow would be.
+    // A workgroup's rows lie in at most two utterances (T_out >= BM): wave 0 merges for the first, wave 1 for the second.
     auto gnr_prologue = [&]() {
-        if (p.gnr_y && tid < 64) {
-            const int cpg = p.N / p.gnr_groups, gl = tid >> 4, j = tid & 15, g = n0 / cpg + gl;
-            const bool live = g < p.gnr_groups && g * cpg < min(p.N, n0 + GEMM_BN);
-            const int b = min(m0 / p.T_out, p.B - 1);
-            const int ncw = p.N >> 6, nrw = p.T_out / p.gnr_tile_rows;
+        if (p.gnr_y && tid < 128) {
+            const int cpg = p.N / p.gnr_groups, gl = (tid & 63) >> 4, j = tid & 15, g = n0 / cpg + gl;
+            const int b = m0 / p.T_out + (tid >> 6);
+            const bool live = g < p.gnr_groups && g * cpg < min(p.N, n0 + GEMM_BN) && b < p.B;
+            const int ncw = p.N >> 6, R = p.gnr_tile_rows;
+            const int t_first = (b * p.T_out) / R, nrw = ((b + 1) * p.T_out - 1) / R - t_first + 1;     // wave tiles touching utterance b
             float n = 0.f, mean = 0.f, m2 = 0.f;
             if (live) {
                 const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
-                for (int k = j; k < nrw * nw; k += 16) {
-                    const int rw = k / nw, w = w_lo + (k - rw * nw);
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(p.gnr_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4);
-                    const float nb = q[0];
-                    if (nb <= 0.f) continue;
-                    const float delta = q[1] - mean, nt = n + nb;
-                    mean += delta * (nb / nt);
-                    m2 += q[2] + delta * delta * (n * nb / nt);
-                    n = nt;
+                // entries in batches of 8 per lane: the loads of a batch are independent (one round trip), the merge order is fixed
+                const int total = nrw * nw;
+                for (int k0 = j; k0 < total; k0 += 16 * 8) {
+                    f32x4 q[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + 16 * e;
+                        const int kc = k < total ? k : j;
+                        const int rw = kc / nw, w = w_lo + (kc - rw * nw), tile = t_first + rw;
+                        const int part = (tile * R) / p.T_out == b ? 0 : 1;
+                        q[e] = *reinterpret_cast<const f32x4*>(p.gnr_stats + ((size_t)(((size_t)tile * 2 + part) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4);
+                        if (k >= total) q[e][0] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float nb = q[e][0];
+                        if (nb <= 0.f) continue;
+                        const float delta = q[e][1] - mean, nt = n + nb;
+                        mean += delta * (nb / nt);
+                        m2 += q[e][2] + delta * delta * (n * nb / nt);
+                        n = nt;
+                    }
                 }
             }
             for (int off = 1; off < 16; off <<= 1) {
@@ -285,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                     n = nt;
                 }
             }
+            float* gs = srow + (tid >> 6) * 8;
             if (j == 0) {
                 if (live && p.gnr_nextra) {            // folded padding: nextra copies of the conv's bias row (closed form)
                     const float ne = (float)p.gnr_nextra[b];
@@ -295,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                         n = nt;
                     }
                 }
-                srow[gl] = mean;
-                srow[4 + gl] = n > 0.f ? 1.0f / sqrtf(m2 / n + p.gnr_eps) : 0.f;
+                gs[gl] = mean;
+                gs[4 + gl] = n > 0.f ? 1.0f / sqrtf(m2 / n + p.gnr_eps) : 0.f;
             }
         }
     };
@@ -354,15 +371,15 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
     __builtin_amdgcn_wave_barrier();
 
-    gemm_epilogue_rows<BM, LN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);     // (gstat shares srow's slot: never both)
+    gemm_epilogue_rows<BM, LN, GN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);     // (gstat shares srow's slot: never both)
 }
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
 // at most one workgroup per CU are latency-bound and lose 4 % with the longer 16x16 issue sequence; B <= 8 serving shapes).
-template <int BM, bool LN, int NST, int MODE, bool M16>
+template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false>
 static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16>;
+    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16, GN>;
     constexpr int lds_bytes = p16_lds_bytes(BM, NST);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -378,6 +395,9 @@ static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
 template <int BM, bool LN, int NST, int MODE>
 static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     // MFMA shape by pipeline depth: 16x16x32 wherever a CU holds more than one workgroup, 32x32x16 on the 4-stage ring (see above)
+    if constexpr (!LN && MODE != 1) {
+        if (a.gn_stats) return launch_p16_shape<BM, LN, NST, MODE, NST != 4, true>(a, s);      // conv feeding a Block1D
+    }
     return launch_p16_shape<BM, LN, NST, MODE, NST != 4>(a, s);
 }
 
@@ -437,11 +457,11 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (a.out16 && ((a.N % 32) || a.ld16 < ew * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
+    if (a.gn_stats && a.fast16) return hipErrorInvalidValue;          // (the opt-in fp16 mode keeps the separate statistics pass)
     if (a.gn_stats) {
-        const int rows_w = gemm_p16_wave_rows(a);
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
         if (a.gn_groups <= 0 || (a.N % a.gn_groups) || (a.N / a.gn_groups) < 32 || ((a.N / a.gn_groups) & 3) || (a.N & 63) || !plain ||
-            (a.T_out % rows_w) || a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f || ln)
+            a.T_out < gemm_p16_wave_rows(a) || a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f || ln)
             return hipErrorInvalidValue;
     }
     int nst = 2;
@@ -449,7 +469,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (a.gnr_y) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
         if (!a.gnr_stats || !a.gnr_gamma || !a.gnr_beta || !a.gnr_mask || a.gnr_groups <= 0 || a.gnr_tile_rows <= 0 || (a.N % a.gnr_groups) ||
-            (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 3) || (a.N & 63) || !plain || (a.T_out % bm) || (a.T_out % a.gnr_tile_rows) || ln ||
+            (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 3) || (a.N & 63) || !plain || a.T_out < bm || a.T_out < a.gnr_tile_rows || ln ||
             ((a.gnr_nextra != nullptr) != (a.gnr_bias_stats != nullptr)) ||
             a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f)
             return hipErrorInvalidValue;

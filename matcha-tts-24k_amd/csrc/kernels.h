@@ -68,17 +68,18 @@ struct GemmArgs {
     const float* out16_mask = nullptr;// [rows] multiplies the out16 copy only (conv consumers read masked rows; out stays as is)
     const _Float16* res16 = nullptr;  // residual as a P16 image (2^11-scaled residual plane) instead of fp32 rows; N % 32 == 0
     int ldr16 = 0;                    // its row stride in halves; may alias out16 (in-place update of the residual stream)
-    // GroupNorm statistics of the output from the epilogue (conv -> Block1D, P16 kernel): per wave tile (BM/2 rows x 64 columns)
-    // and per group slice inside it (<= 2: needs (N / gn_groups) >= 32) an entry (n, mean, M2, -) at
-    // gn_stats[((row_wave * (N/64) + col_wave) * 2 + slice) * 4]; launch_gn_apply merges them (tile_stats).  Needs plain rows,
-    // T_out % (BM/2) == 0 (gemm_p16_wave_rows), N % 64 == 0 and an epilogue of bias only.
+    // GroupNorm statistics of the output from the epilogue (conv -> Block1D, P16 kernel): per wave tile (R = BM/2 rows x 64
+    // columns), per PART of it (part 0 = the rows of the tile's first utterance, part 1 = those of the next one: T_out >= R, so a
+    // tile touches at most two) and per group slice (<= 2: needs (N / gn_groups) >= 32) an entry (n, mean, M2, -) at
+    // gn_stats[(((tile * 2 + part) * (N/64) + col_wave) * 2 + slice) * 4]; launch_gn_apply merges them (tile_stats, tile_rows = R
+    // = gemm_p16_wave_rows).  Needs plain rows, N % 64 == 0 and an epilogue of bias only; any T_out >= R.
     float* gn_stats = nullptr;
     int gn_groups = 0;
     const int* gn_nrows = nullptr;    // [B] rows of each utterance that enter the statistics (the GroupNorm kernels' nrows); null = T_out
     // Block1D tail in the epilogue (ResNet output, P16 kernel): c += Mish(GroupNorm(y)[row][n]) * gnr_mask[row], where y is the
     // second conv's fp32 output and its statistics are the tile entries that conv's epilogue left (gn_stats there): this GEMM
     // is the ResNet's 1x1 residual conv, so the sum is the ResNet output (reference decoder.py:58-63) and no gn_apply pass or
-    // residual round trip remains.  Needs T_out % BM == 0 (a workgroup's rows in one utterance) and N / gnr_groups >= 32.
+    // residual round trip remains.  Needs T_out >= BM (a workgroup's rows in at most two utterances) and N / gnr_groups >= 32.
     const float* gnr_y = nullptr;     // [M][N] fp32 rows (ld = N)
     const float* gnr_stats = nullptr; // entries as GemmArgs::gn_stats of the producing conv
     int gnr_tile_rows = 0, gnr_groups = 0;

@@ -78,7 +78,9 @@ static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
 // The sticky range flag of a call = the first word of its workspace, cleared here (include/mtts.h "range guard").
 static int begin_call(mtts_ctx* c, void* d_ws, hipStream_t s) {
     c->cur_flag = static_cast<unsigned int*>(d_ws);
-    HIP_OK(hipMemsetAsync(d_ws, 0, 256, s));
+    // a kernel, not hipMemsetAsync: a captured memset node of one HIP graph was seen to write another instantiated graph's
+    // bytes (pointer-like words in this header) after a second context captured its own graph (ROCm 7.2); kernel nodes are safe
+    HIP_OK(launch_fill_cols(static_cast<float*>(d_ws), 1, 64, 0, 64, 0.f, s));
     return 0;
 }
 
@@ -513,7 +515,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
         d.XM16 = reinterpret_cast<_Float16*>(ws.f(M0 * round_up(2 * g.n_feats, 64)));
     }
     d.gnp = ws.f((size_t)B * gn_chunks_max(T) * 8 * 2);
-    d.gns = ws.f((M0 / 32 + 1) * (size_t)((cmax + 63) / 64) * 8);
+    d.gns = ws.f((M0 / 32 + 2) * 2 * (size_t)((cmax + 63) / 64) * 8);
     d.ew = (d.p16 && c->half16) ? 1 : 2;
     d.ldx = round_up(2 * g.n_feats, c->half16 ? 64 : GEMM_BK);
     d.ldv = round_up(g.n_feats, 4);
@@ -776,13 +778,14 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
     return 0;
 }
 
-// GroupNorm statistics from the conv GEMM's epilogue instead of a gn_partial pass over its output (gemm_epilogue.h): needs
-// whole wave tiles per utterance and groups of >= 32 channels; MTTS_GN_FUSE=0 keeps the separate pass (A/B runs).
+// GroupNorm statistics from the conv GEMM's epilogue instead of a gn_partial pass over its output (gemm_epilogue.h): entries per
+// wave tile and utterance part, so an utterance must be at least one wave tile long, and groups of >= 32 channels;
+// MTTS_GN_FUSE=0 keeps the separate pass (A/B runs).  Returns the wave-tile height (the consumers' tile_rows) or 0.
 static int gn_fuse_rows(const GemmArgs& a, int C, int G, int T) {
     static const bool on = [] { const char* e = getenv("MTTS_GN_FUSE"); return !(e && e[0] == '0'); }();
-    if (!on || !a.a16_0 || (C % 64) || (C % G) || (C / G) < 32 || ((C / G) & 3)) return 0;
+    if (!on || !a.a16_0 || a.fast16 || (C % 64) || (C % G) || (C / G) < 32 || ((C / G) & 3)) return 0;
     const int rows = gemm_p16_wave_rows(a);
-    return (T % rows) == 0 ? rows : 0;
+    return T >= rows ? rows : 0;
 }
 
 // ---- P16 decoder: the same network with every GEMM on pre-split operands (gemm_p16.hip).  Each producer writes the P16
@@ -819,7 +822,7 @@ static int resnet_block_p16(mtts_ctx* c, DecBufs& d, const ResnetW& r, const _Fl
     rc.a16_0 = in0; rc.lda16_0 = d.ew * c0; rc.c0 = c0; rc.a16_1 = in1; rc.lda16_1 = d.ew * c1; rc.c1 = c1;
     (void)out;                                                        // no fp32 copy: x lives on as its image only
     static const bool tail_on = [] { const char* e = getenv("MTTS_GN_TAIL"); return !(e && e[0] == '0'); }();   // A/B runs
-    if (tail_on && fr2 && (T % (2 * gemm_p16_wave_rows(rc))) == 0) {
+    if (tail_on && fr2 && T >= 2 * gemm_p16_wave_rows(rc)) {      // a workgroup's rows in at most two utterances
         // The 1x1 residual conv finishes the block: its epilogue adds Mish(GroupNorm(conv2 output)) * mask from the tile
         // statistics conv2 left, and writes x's image + LayerNorm moments -- no gn_apply pass, no residual round trip.
         rc.gnr_y = d.Y; rc.gnr_stats = d.gns; rc.gnr_tile_rows = fr2; rc.gnr_groups = 8;

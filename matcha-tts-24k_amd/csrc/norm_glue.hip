@@ -240,19 +240,33 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
         float n = 0.f, mean = 0.f, m2 = 0.f;
         if (g < p.G && p.tile_stats) {
             // entries left by the producing GEMM's epilogue: per wave tile (tile_rows rows x 64 columns) and group slice
-            const int ncw = p.C >> 6, nrw = p.T / p.tile_rows;
+            const int ncw = p.C >> 6, R = p.tile_rows;
+            const int t_first = (b * p.T) / R, nrw = ((b + 1) * p.T - 1) / R - t_first + 1;           // wave tiles touching utterance b
             const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
-            for (int k = j; k < nrw * nw; k += L) {
-                const int rw = k / nw, w = w_lo + (k - rw * nw);
-                const int slice = g - (w * 64) / cpg;
-                const f32x4 q = *reinterpret_cast<const f32x4*>(p.tile_stats + ((size_t)(((size_t)b * nrw + rw) * ncw + w) * 2 + slice) * 4);
-                const float nb = q[0];
-                if (nb <= 0.f) continue;
-                const float delta = q[1] - mean;
-                const float nt = n + nb;
-                mean += delta * (nb / nt);
-                m2 += q[2] + delta * delta * (n * nb / nt);
-                n = nt;
+            // entries in batches of 4 per lane: a batch's loads are independent (one round trip), the merge order is fixed
+            const int total = nrw * nw;
+            for (int k0 = j; k0 < total; k0 += L * 4) {
+                f32x4 q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + L * e;
+                    const int kc = k < total ? k : j;
+                    const int rw = kc / nw, w = w_lo + (kc - rw * nw), tile = t_first + rw;
+                    const int part = (tile * R) / p.T == b ? 0 : 1;
+                    const int slice = g - (w * 64) / cpg;
+                    q[e] = *reinterpret_cast<const f32x4*>(p.tile_stats + ((size_t)(((size_t)tile * 2 + part) * ncw + w) * 2 + slice) * 4);
+                    if (k >= total) q[e][0] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float nb = q[e][0];
+                    if (nb <= 0.f) continue;
+                    const float delta = q[e][1] - mean;
+                    const float nt = n + nb;
+                    mean += delta * (nb / nt);
+                    m2 += q[e][2] + delta * delta * (n * nb / nt);
+                    n = nt;
+                }
             }
         } else if (g < p.G) {
             const int Tb = p.nrows ? min(p.T, p.nrows[b]) : p.T;
@@ -373,7 +387,7 @@ hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     // stats_out needs whole 16-thread DPP rows per 64-column slice and one thread row per wave-aligned offset
     if (a.stats_out && ((a.C & 63) || ((a.C / 4) & 15))) return hipErrorInvalidValue;
     if (a.out16 && ((a.C & 31) || a.ld16 < (a.half16 ? 1 : 2) * a.C || (a.ld16 & 3))) return hipErrorInvalidValue;
-    if (a.tile_stats && (a.tile_rows <= 0 || (a.T % a.tile_rows) || (a.C & 63) || (a.C / a.G) < 32)) return hipErrorInvalidValue;
+    if (a.tile_stats && (a.tile_rows <= 0 || a.T < a.tile_rows || (a.C & 63) || (a.C / a.G) < 32)) return hipErrorInvalidValue;
     if ((a.nextra != nullptr) != (a.bias_stats != nullptr)) return hipErrorInvalidValue;
     GnApplyArgs b = a;
     b.chunk_rows = gn_chunk_rows(a.B, a.T);
