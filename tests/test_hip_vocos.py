@@ -60,3 +60,31 @@ def test_pipeline_tail_to_waveform(env):
     assert (wav - ref).abs().max() < 2e-4
     with pytest.raises(RuntimeError):
         wrapper(mel)          # CPU mel: no fallback
+
+
+def test_istft_stage_against_torch_istft():
+    """Independent of the restated oracle: with `head.out.weight` = 0 the head's spectrum is its bias in every frame, whatever the
+    backbone does, so the audio is torch.istft of a stationary spectrogram -- an analytic check of spec_polar (exp / clip / cos /
+    sin), the inverse-DFT-times-window GEMM, the overlap-add with the squared-window envelope and the centre trim against
+    PyTorch's own istft (n_fft 1024, hop 256, periodic hann, center=True: reference vocos24k/config.yaml:18-24)."""
+    if not torch.cuda.is_available():
+        pytest.fail("a HIP device is required for -m gpu tests (no CPU fallback exists)")
+    syn, voc = sub("synthetic"), sub("vocoder")
+    sd = syn.make_vocos_state_dict(seed=11)
+    n_fft, hop, nb, T = 1024, 256, 513, 40
+    g = torch.Generator().manual_seed(7)
+    logmag = torch.rand(nb, generator=g) * 4.0 - 3.0
+    logmag[5] = 6.0                                            # exp(6) = 403 > the head's clip at 1e2
+    phase = (torch.rand(nb, generator=g) * 2 - 1) * 3.0
+    sd["head.out.weight"] = torch.zeros_like(sd["head.out.weight"])
+    sd["head.out.bias"] = torch.cat([logmag, phase])
+    wrapper = voc.load_model("cuda", state_dict=sd)
+    mel = torch.randn(2, 100, T, generator=g)
+    out = wrapper(mel.cuda()).cpu()
+    mag = torch.clip(torch.exp(logmag), max=1e2)
+    spec = (mag * torch.cos(phase) + 1j * mag * torch.sin(phase)).to(torch.complex64)
+    ref = torch.istft(spec[None, :, None].expand(1, nb, T).contiguous(), n_fft, hop_length=hop, win_length=n_fft,
+                      window=torch.hann_window(n_fft), center=True)
+    assert out.shape == (2, hop * (T - 1)) and ref.shape == (1, hop * (T - 1))
+    scale = float(ref.abs().max())
+    assert (out[0] - ref[0]).abs().max() < 2e-5 * scale and torch.equal(out[0], out[1])
