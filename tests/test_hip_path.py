@@ -336,7 +336,7 @@ def test_prod_odd_lengths_p16_vs_fp32_operand_path(lengths, prod, synthetic, dev
     assert maxabs(out["mel"], ref["mel"]) < 2e-4
 
 
-def test_config2_batch32_properties(prod, synthetic, dev):
+def test_config2_batch32_properties(prod, synthetic, oracle, dev):
     """BASELINE config #2 (B=32, Tx=128, euler/10) at full size: size-independent checks.
     All utterances of a batch are independent (per-sample norms and attention), so row b of the batched result must
     equal the same utterance synthesised alone with its slice of the noise; and the output must be deterministic."""
@@ -351,6 +351,11 @@ def test_config2_batch32_properties(prod, synthetic, dev):
     for b in (0, 17, 31):
         solo = model.synthesise(x[b:b + 1].to(dev), x_len[b:b + 1].to(dev), 10, speaker=0, z=z[b:b + 1])["mel"]
         assert maxabs(out[b:b + 1], solo) < 1e-4
+    # rows other than the golden one against the oracle run here on the same ids and noise slice (utterances are independent)
+    for b in (7, 19):
+        with torch.inference_mode():
+            ref = oracle.synthesise(sd, hp, x[b:b + 1], x_len[b:b + 1], 10, speaker=0, solver="euler", z=z[b:b + 1].cpu())
+        assert maxabs(out[b:b + 1], ref["mel"]) < MEL_TOL, b
     g = np.load(GOLDEN / "prod_synth.npz")   # utterance 0 of the batch is the golden single utterance
     x1, _, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
     if torch.equal(x1, x[:1]):
