@@ -117,7 +117,7 @@ class CFM(nn.Module):
         self.sigma_min = hp.sigma_min
         self.use_mu_prior = hp.use_mu_prior
         self.fold_padding = os.environ.get("MTTS_FOLD", "1") != "0"
-        self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "8"))
+        self.fold_align = int(os.environ.get("MTTS_FOLD_ALIGN", "1"))
         # HIP graphs for launch-bound sizes (SURVEY section 7 "launch-bound small batches"): "auto" = when the estimator holds
         # at most graph_max_rows rows (B * rows per utterance), "1" always, "0" never
         self.graph_mode = os.environ.get("MTTS_GRAPH", "auto")
@@ -151,10 +151,9 @@ class CFM(nn.Module):
 
     def fold_plan(self, T: int, y_max: Optional[int]) -> Optional[int]:
         """Rows per utterance for the folded estimator (include/mtts.h mtts_cfm_solve_folded), or None to run all T frames.
-        ``fold_padding`` (attribute; env MTTS_FOLD=0 turns the default off) and ``fold_align`` (MTTS_FOLD_ALIGN, default 8 rows at
-        the coarsest level: measured best at B = 32 -- 336 / 168 rows for 320 valid frames fill the chip's 256 CUs with whole
-        rounds of tiles; 32 keeps whole wave tiles per utterance for the GroupNorm statistics of the conv epilogues but runs
-        384 / 192 rows) are plain attributes like ``solver``."""
+        ``fold_padding`` (attribute; env MTTS_FOLD=0 turns the default off) and ``fold_align`` (MTTS_FOLD_ALIGN, rows at the coarsest
+        level; default 1 = the minimum, 322 / 161 rows for 320 valid frames: no kernel needs whole tiles per utterance, and
+        every extra row is pure cost -- 29.1 / 29.4 / 29.8 / 33.5 ms per step at align 2 / 4 / 8 / 32 on one box) are plain attributes like ``solver``."""
         if not self.fold_padding or y_max is None:
             return None
         t_fold = self._rt.ready().fold_rows(y_max, self.fold_align)

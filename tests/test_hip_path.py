@@ -399,12 +399,12 @@ def test_tiny_folded_padding_equals_full_padding(tiny, synthetic, oracle, dev, l
 
 
 def test_folding_is_what_synthesise_runs_at_prod_shapes(prod, synthetic, dev):
-    """The default plan at BASELINE config #2's shape: 320 valid of 640 frames -> 336 rows per utterance (160 + 1 rounded to a
-    multiple of 8 at the coarse level, doubled); the golden tests above therefore already exercise the folded estimator.  Here:
+    """The default plan at BASELINE config #2's shape: 320 valid of 640 frames -> 322 rows per utterance (160 + 1 at the
+    coarse level, doubled); the golden tests above therefore already exercise the folded estimator.  Here:
     folded == unfolded at production width (P16 kernels), ragged, with whole wave tiles per utterance (align 32: GroupNorm
     statistics from the conv epilogues, fused ResNet tail) and without (statistics from the separate pass)."""
     hp, sd, model = prod
-    assert model.decoder.fold_padding and model.decoder.fold_plan(640, 320) == 336
+    assert model.decoder.fold_padding and model.decoder.fold_plan(640, 320) == 322
     assert model.decoder.fold_plan(640, 639) is None and model.decoder.fold_plan(2, 1) is None
     lengths = [128, 100, 77, 128]
     x, x_len, _ = synthetic.make_inputs(hp, 4, 128, seed=1234, lengths=lengths)
