@@ -62,12 +62,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             BUILD_MODE = f"reused {LIB.name} (newer than every source and header)"
             return LIB
     # -ffp-contract=off: keep the reference's rounding points (no silent FMA fusion in the element-wise math).
-    # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent fp32 ops into v_pk_mul_f32 / v_pk_add_f32; in the
-    #   split-bf16 GEMM staging (LayerNorm prologue -> bf16 split -> LDS store) that produced sporadically wrong values in
-    #   lanes 48-63 of a wave on gfx950 (a missing wait state after the packed op; reproduced with tools/_dbg_stats.py,
-    #   gone with scalar fp32 ops).  Packed fp32 VALU is also slower beside MFMAs (cdna_hip_programming.md).
+    # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent fp32 ops into v_pk_mul_f32 / v_pk_add_f32.  With SLP on,
+    #   gemm_f32_kernel<*, *, NORM=true, TERMS=6|2> returns grossly wrong rows (error 0.6 at magnitude 7) when its LayerNorm
+    #   statistics come from partial moments (a_part): DETERMINISTIC repro = build with MTTS_SLP=1 and run
+    #   tests/test_hip_kernels.py::test_layernorm_stats_travel_through_epilogue[bf16x6|f16x3s] (2 of 75 kernel tests fail, every
+    #   run; all other translation units pass with SLP on).  The packed ops sit in the normalise -> split -> LDS-store chain
+    #   ((x - mean) * rstd as v_pk_mul_f32 op_sel:[0,1], the split's subtractions as v_pk_add_f32 neg_lo/neg_hi); a scan for
+    #   VALU -> DPP wait-state violations found none, the root cause inside the compiler's output is not isolated.  Packed fp32
+    #   VALU is an anti-lever beside MFMAs anyway (MI355X_MICROARCH.md cycle table; 29.98 vs 29.8 ms/step), so the flag stays
+    #   on for every translation unit.
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+    slp = [] if os.environ.get("MTTS_SLP") == "1" else ["-fno-slp-vectorize"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *slp, "-fPIC",
              *os.environ.get("MTTS_HIPCC_EXTRA", "").split()]
     # one translation unit per process (the GEMM files instantiate dozens of kernels each), objects in build/, then one link
     objdir = HERE / "build"
