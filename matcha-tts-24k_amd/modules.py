@@ -125,6 +125,7 @@ class CFM(nn.Module):
         self.graph_bucket = 64
         object.__setattr__(self, "_graphs", collections.OrderedDict())
         self.graph_cache_entries = int(os.environ.get("MTTS_GRAPH_CACHE", "24"))
+        self.graph_cache_bytes = int(float(os.environ.get("MTTS_GRAPH_CACHE_GB", "4")) * (1 << 30))   # static buffers held
         self.graph_replays = 0
         object.__setattr__(self, "_rt", rt)
         self.estimator = Estimator()
@@ -225,9 +226,11 @@ class CFM(nn.Module):
                 e["graph"] = g
             finally:
                 hip.set_frame_limits(None)
+            e["bytes"] = sum(int(e[k].numel()) * e[k].element_size() for k in ("z", "mu", "ws", "out"))
             self._graphs[key] = e
-            while len(self._graphs) > self.graph_cache_entries:
-                self._graphs.popitem(last=False)
+            while len(self._graphs) > 1 and (len(self._graphs) > self.graph_cache_entries or
+                                             sum(v["bytes"] for v in self._graphs.values()) > self.graph_cache_bytes):
+                self._graphs.popitem(last=False)          # least recently used graph and its buffers
         else:
             self._graphs.move_to_end(key)
         w = min(T, rows)
