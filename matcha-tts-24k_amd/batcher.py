@@ -31,6 +31,7 @@ import torch
 class Request:
     ids: Sequence[int]                      # phoneme ids of one utterance
     speaker: int = 0
+    voice_mix: Optional[Sequence[Tuple[int, float]]] = None    # [(id, weight), ...] as reference server.py:96-101; overrides speaker
     solver: str = "midpoint"
     n_timesteps: int = 4
     scale_correction: float = 1.0
@@ -146,10 +147,10 @@ class FrameBudgetBatcher:
         for b, r in enumerate(batch):
             x[b, :len(r.ids)] = torch.as_tensor(r.ids, dtype=torch.long)
         x_len = torch.tensor([len(r.ids) for r in batch], dtype=torch.long)
-        spk = torch.tensor([r.speaker for r in batch], dtype=torch.long)
         head = batch[0]
         self.model.decoder.solver = head.solver
-        out = self.model.synthesise(x.to(dev), x_len.to(dev), head.n_timesteps, speaker=spk.to(dev),
+        emb = self.model.speaker_rows([list(r.voice_mix) if r.voice_mix is not None else r.speaker for r in batch])
+        out = self.model.synthesise(x.to(dev), x_len.to(dev), head.n_timesteps, speaker_embeddings=emb,
                                     scale_correction=[r.scale_correction for r in batch],
                                     length_scale=[r.length_scale for r in batch], per_request_padding=True)
         lens = out["mel_lengths"].tolist()

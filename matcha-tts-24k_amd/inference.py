@@ -103,9 +103,10 @@ class MatchaTTSInfer(nn.Module):
     range_policy = "rerun"
 
     def synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
-                   debug=False, z=None, sync_max=None, per_request_padding=False):
+                   debug=False, z=None, sync_max=None, per_request_padding=False, speaker_embeddings=None):
         """``_synthesise`` + the range guard: one read of the sticky device flag per call (a stream synchronisation)."""
-        args = (x, x_lengths, n_timesteps, speaker, voice_mix, scale_correction, length_scale, debug, z, sync_max, per_request_padding)
+        args = (x, x_lengths, n_timesteps, speaker, voice_mix, scale_correction, length_scale, debug, z, sync_max, per_request_padding,
+                speaker_embeddings)
         rt = self._rt
         if rt.use_wide:                       # a previous call or the weights already needed the wide arithmetic
             return self._synthesise(*args)
@@ -130,14 +131,32 @@ class MatchaTTSInfer(nn.Module):
         return self._synthesise(*args)
 
     @torch.inference_mode()
+    def speaker_rows(self, voices):
+        """One (e_enc, e_dur) row per entry of ``voices``: an int speaker id, or a voice mix ``[(id, weight), ...]`` combined as
+        ``mix_speakers`` does (reference inference.py:57-76).  Returns two [len(voices), spk_emb_dim] device tensors."""
+        dev = next(self.parameters()).device
+        hip = self._rt.ready()
+        enc, dur = [], []
+        for v in voices:
+            if isinstance(v, (list, tuple)):
+                e, d = self.mix_speakers(v)
+            else:
+                ids = torch.tensor([int(v)], device=dev, dtype=torch.long)
+                e, d = hip.speaker_embedding(0, ids), hip.speaker_embedding(1, ids)
+            enc.append(e)
+            dur.append(d)
+        return torch.cat(enc, 0), torch.cat(dur, 0)
+
+    @torch.inference_mode()
     def _synthesise(self, x, x_lengths, n_timesteps, speaker=0, voice_mix=None, scale_correction=1.0, length_scale=1.0,
-                    debug=False, z=None, sync_max=None, per_request_padding=False):
+                    debug=False, z=None, sync_max=None, per_request_padding=False, speaker_embeddings=None):
         """Text ids -> mel (reference inference.py:78-183).  Returns ``{"mel": [B, n_feats, T_valid_max]}`` (+ the
         reference's debug tensors when ``debug``).
 
         ``z``: explicit noise [B, n_feats, T_pad], or a callable ``T_pad -> noise``; default = the device seed-42
         generator like the reference.  ``sync_max``: callable mapping this process's maximum fine length to the
         batch-wide one (data-parallel shards must pad like the whole batch, see dp.py).
+        ``speaker_embeddings``: per-utterance ``(e_enc, e_dur)`` rows, e.g. from ``speaker_rows`` (overrides speaker / voice_mix).
         ``per_request_padding``: the reference derives the padded length, and with it the GroupNorm statistics, the
         attention key set and the noise shape, from the longest utterance of the call, so a request's mel depends on what
         it is batched with.  With this flag every utterance is padded (logically) to its OWN length: each row of a ragged
@@ -146,7 +165,9 @@ class MatchaTTSInfer(nn.Module):
         hip = self._rt.ready()
         dev = x.device
         B = x.shape[0]
-        if voice_mix is not None:
+        if speaker_embeddings is not None:      # (e_enc, e_dur) [B, spk_emb_dim] each: a batch that mixes plain voices and voice mixes
+            e_enc, e_dur = speaker_embeddings
+        elif voice_mix is not None:
             e_enc, e_dur = self.mix_speakers(voice_mix)
         else:
             ids = torch.as_tensor(speaker, dtype=torch.long, device=dev).reshape(-1)

@@ -108,6 +108,32 @@ def test_per_utterance_scale_factors_equal_separate_calls(cfg4, synthetic, dev):
         assert int(out["mel_lengths"][b]) == int(solo["mel_lengths"][0])
 
 
+def test_batcher_mixes_plain_voices_and_voice_mixes(cfg4, synthetic, dev):
+    """One batch carrying a plain voice, a two-voice mix (reference server.py:96-101, inference.py:57-76) and another plain
+    voice, each with its own scale correction and speed: every request gets the mel of its own `synthesise` call."""
+    hp, sd, model, vocoder, voc_sd, inf = cfg4
+    bt, sv = sub("batcher"), sub("serving")
+    reqs = [dict(voice=3, speed=1.0), dict(voice="2(70)+6(30)", speed=1.25), dict(voice=9, speed=0.8)]
+    lengths = [30, 22, 41]
+    ids = [synthetic.make_inputs(hp, 1, n, seed=70 + i)[0][0].tolist() for i, n in enumerate(lengths)]
+    model.decoder.solver = "midpoint"
+    with bt.FrameBudgetBatcher(model, max_batch=8, max_tokens=4096, max_wait_ms=50.0) as q:
+        futs = []
+        for r, tok in zip(reqs, ids):
+            p = sv.request_params(**r)
+            futs.append((p, q.submit(tok, speaker=p.speaker, voice_mix=p.voice_mix, solver="midpoint", n_timesteps=2,
+                                     scale_correction=p.scale_correction, length_scale=p.length_scale)))
+        results = [(p, f.result(timeout=120)) for p, f in futs]
+        assert q.batches_run == 1
+    for (p, res), tok in zip(results, ids):
+        x = torch.tensor([tok], device=dev)
+        x_len = torch.tensor([len(tok)], device=dev)
+        solo = model.synthesise(x, x_len, 2, speaker=p.speaker, voice_mix=p.voice_mix, scale_correction=p.scale_correction,
+                                length_scale=p.length_scale)
+        assert res["mel_length"] == int(solo["mel_lengths"][0])
+        assert maxabs(res["mel"][None], solo["mel"][:, :, :res["mel_length"]]) < 5e-5
+
+
 def test_config5_closed_loop_short_run(dev):
     """tools/load_sim.py (closed-loop users over FrameBudgetBatcher, Vocos + trim per request) for a few seconds at 1 and 6
     users: every request is answered, latency per audio-second is finite and positive, batches form under concurrency."""

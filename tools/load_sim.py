@@ -48,7 +48,8 @@ def percentile(v, q):
 def run_level(batcher, inference, hp, users, seconds, seed, time_scale=1.0):
     stop_at = time.monotonic() + seconds
     lat, lat_per_s, audio_s, lock = [], [], [], threading.Lock()
-    voices_of = {}
+    serving = importlib.import_module(PKG + ".serving")
+    voices_of = {"en-us": [{"id": "0(50)+1(50)"}]}            # the load test's extra "Voice mix" voice (load_test.py:17)
     for v in inference.VOICES:
         voices_of.setdefault(v["lang"], []).append(v)
 
@@ -61,9 +62,9 @@ def run_level(batcher, inference, hp, users, seconds, seed, time_scale=1.0):
             n_tok = max(1, min(MAX_TOKENS, round(chars * TOKENS_PER_CHAR)))
             ids = [rng.randrange(hp.n_vocab) for _ in range(n_tok)]
             t0 = time.monotonic()
-            res = batcher.submit(ids, speaker=int(voice["id"]) % hp.n_spks, solver=inference.DEFAULT_ODE_SOLVER,
-                                 n_timesteps=inference.DEFAULT_NUM_STEPS, scale_correction=voice["scale_correction"],
-                                 length_scale=1.0).result()
+            p = serving.request_params(voice=voice["id"], speed=1.0)            # the handler's mapping (server.py:96-115)
+            res = batcher.submit(ids, speaker=p.speaker, voice_mix=p.voice_mix, solver=p.solver, n_timesteps=p.n_timesteps,
+                                 scale_correction=p.scale_correction, length_scale=p.length_scale).result()
             dt = time.monotonic() - t0
             dur = (len(res["audio"]) if "audio" in res else res["mel_length"] * inference.STD_RES_HOP_LENGTH) / inference.SAMPLE_RATE
             with lock:
