@@ -196,7 +196,9 @@ class CFM(nn.Module):
     def _graph_wanted(self, B: int, y_max: int) -> bool:
         if self.graph_mode == "0" or not self.fold_padding:
             return False
-        return self.graph_mode == "1" or B * self._graph_rows(y_max) <= self.graph_max_rows
+        # auto: few utterances (the host's launch cost is what a graph saves; the kernels take the same time) and few enough
+        # (B, bucket) combinations that captures (~15 ms each, first use only) stay rare
+        return self.graph_mode == "1" or (B <= 8 and B * self._graph_rows(y_max) <= self.graph_max_rows)
 
     def _solve_on_graph(self, hip, mu, z, n_timesteps, t_out, out_scale, out_shift, t_len, y_lengths, y_max):
         """One ODE solve as ONE graph launch: the ~100 kernels per evaluation are captured once per (batch, row bucket, solver,
