@@ -108,6 +108,32 @@ def test_per_utterance_scale_factors_equal_separate_calls(cfg4, synthetic, dev):
         assert int(out["mel_lengths"][b]) == int(solo["mel_lengths"][0])
 
 
+def test_pipeline_signature_and_outputs(cfg4, synthetic, dev, monkeypatch):
+    """`pipeline(model, vocoder, text, speaker, voice_mix, n_timesteps, scale_correction, length_scale, debug)` as the
+    reference's CLI / server call it (reference inference.py:233-257, cli.py, server.py:116), with the phonemizer (a CPU front
+    end outside the path) replaced by a stub: a trimmed 1-D host waveform; with debug=True the (waveform, encoder waveform,
+    [(phone, raw duration, duration)]) triple."""
+    hp, sd, model, vocoder, voc_sd, inf = cfg4
+    ids = synthetic.make_inputs(hp, 1, 20, seed=3)[0][0].tolist()
+
+    def fake_process_text(text, language):
+        assert language == "en-us"
+        x = torch.tensor(ids, dtype=torch.long, device=dev)[None]
+        return {"x_orig": text, "x": x, "x_lengths": torch.tensor([len(ids)], device=dev), "x_phones": "a" * len(ids), "x_phone_ids": ids}
+
+    monkeypatch.setattr(inf, "process_text", fake_process_text)
+    model.decoder.solver = inf.DEFAULT_ODE_SOLVER
+    wav = inf.pipeline(model, vocoder, "hello", speaker=3, n_timesteps=2, scale_correction=1.03, length_scale=0.9)
+    assert wav.device.type == "cpu" and wav.dim() == 1 and wav.numel() > 0 and float(wav.abs().max()) <= 1.0 + 1e-6
+    out = model.synthesise(torch.tensor([ids], device=dev), torch.tensor([len(ids)], device=dev), 2, speaker=3,
+                           scale_correction=1.03, length_scale=0.9)
+    full = inf.to_waveform(out["mel"], vocoder)
+    assert wav.numel() <= full.numel() and (full.numel() - wav.numel()) % 240 == 0           # whole 10 ms windows trimmed
+    assert torch.allclose(wav, full[: wav.numel()], atol=1e-6)
+    w2, enc_wav, pairs = inf.pipeline(model, vocoder, "hello", voice_mix=[(0, 0.5), (1, 0.5)], n_timesteps=2, debug=True)
+    assert w2.dim() == 1 and enc_wav.dim() == 1 and len(pairs) == len(ids) and all(len(p) == 3 for p in pairs)
+
+
 def test_batcher_mixes_plain_voices_and_voice_mixes(cfg4, synthetic, dev):
     """One batch carrying a plain voice, a two-voice mix (reference server.py:96-101, inference.py:57-76) and another plain
     voice, each with its own scale correction and speed: every request gets the mel of its own `synthesise` call."""
