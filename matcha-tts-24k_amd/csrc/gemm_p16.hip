@@ -396,9 +396,9 @@ template <int BM, bool LN, int NST, int MODE>
 static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
     // MFMA shape by pipeline depth: 16x16x32 wherever a CU holds more than one workgroup, 32x32x16 on the 4-stage ring (see above)
     if constexpr (!LN && MODE != 1) {
-        if (a.gn_stats) return launch_p16_shape<BM, LN, NST, MODE, (NST < 4), true>(a, s);      // conv feeding a Block1D
+        if (a.gn_stats) return launch_p16_shape<BM, LN, NST, MODE, !(BM == 64 && NST == 4), true>(a, s);      // conv feeding a Block1D
     }
-    return launch_p16_shape<BM, LN, NST, MODE, (NST < 4)>(a, s);
+    return launch_p16_shape<BM, LN, NST, MODE, !(BM == 64 && NST == 4)>(a, s);
 }
 
 template <int BM, bool LN, int NST = 2>
