@@ -326,9 +326,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     range_bad |= out_of_f16_range(o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv, o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = o[t][4 * g4 + e] * inv;
-                        hh[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-                        ll[e] = (_Float16)fminf(fmaxf((v - (float)hh[e]) * p.out_lscale, -65504.f), 65504.f);
+                        _Float16 a, b;
+                        split_f16(o[t][4 * g4 + e] * inv, p.out_lscale, a, b);
+                        hh[e] = a;
+                        ll[e] = b;
                     }
                     if constexpr (HALF) {
                         *reinterpret_cast<f16x4*>(op + t * 32 + 8 * g4 + 4 * h) = hh;

@@ -8,10 +8,17 @@ namespace mtts {
 constexpr float F16_RES_SCALE = 2048.0f;   // fp16 two-term split: the residual is stored times 2^11
 
 // x ~ h + l / 2^11 with h = fp16(x) (saturating) and l the scaled fp16 residual: 22 significand bits
+// (the residual is taken from the CLAMPED value: |xc - h| <= ulp(h)/2, so it needs no clamp of its own; a saturated operand is
+// reported through the range flag, device_utils.h out_of_f16_range)
 __device__ __forceinline__ void split_f16(float x, _Float16& h, _Float16& l) {
-    const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
+    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     h = (_Float16)xc;
-    l = (_Float16)fminf(fmaxf((x - (float)h) * F16_RES_SCALE, -65504.f), 65504.f);
+    l = (_Float16)((xc - (float)h) * F16_RES_SCALE);
+}
+__device__ __forceinline__ void split_f16(float x, float lscale, _Float16& h, _Float16& l) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    h = (_Float16)xc;
+    l = (_Float16)((xc - (float)h) * lscale);
 }
 
 // Range guard of the fp16 split: an operand beyond +-65504 saturates (h clamps), which the caller must learn about.  Producers
@@ -26,7 +33,24 @@ __device__ __forceinline__ void raise_range_flag(unsigned int* flag, bool bad) {
 // sin(y)^2 for the SnakeBeta epilogue: 3-constant Cody-Waite reduction by pi/2 to r in [-pi/4, pi/4] and the minimax sine
 // kernel; in odd quadrants sin(y)^2 = cos(r)^2 = 1 - sin(r)^2, so one polynomial serves both (sin(r)^2 <= 1/2: the
 // subtraction is benign).  ~1 ulp of sinf(y)^2 for |y| < 1e4 (arguments here are O(10)), a quarter of the library sinf.
+// sin(y)^2 = (1 - cos(2y)) / 2 with the hardware cosine (v_cos_f32 takes revolutions; v_fract_f32 reduces the argument first):
+// 4 VALU instructions instead of the ~16 of the polynomial below.  The FeedForward's first projection spends half of its
+// workgroup lifetime in this epilogue (profiles/r02_kstamp.log).  Absolute error of v_cos_f32 ~1e-6, i.e. ~5e-7 on sin^2 (the
+// polynomial: ~1e-7): the mel error against the goldens is unchanged (5.6e-5 / 3.4e-5 / 4.1e-5) and the
+// kernel test against fp64 holds its 1e-5.  -DMTTS_SNAKE_POLY builds the polynomial (3-constant Cody-Waite + minimax sine).
+__device__ __forceinline__ float sin_sq_hw(float y) {
+    const float t = __builtin_amdgcn_fractf(y * 0.31830988618379067154f);     // 2y / (2 pi), reduced to [0, 1)
+    return fmaf(-0.5f, __builtin_amdgcn_cosf(t), 0.5f);
+}
+__device__ __forceinline__ float sin_sq_poly(float y);
 __device__ __forceinline__ float sin_sq(float y) {
+#ifdef MTTS_SNAKE_POLY
+    return sin_sq_poly(y);
+#else
+    return sin_sq_hw(y);
+#endif
+}
+__device__ __forceinline__ float sin_sq_poly(float y) {
     const float n = rintf(y * 0.63661977236758134308f);
     float r = fmaf(n, -1.5707962513e+00f, y);       // pi/2 split: hi, mid, lo
     r = fmaf(n, -7.5497894159e-08f, r);

@@ -198,9 +198,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
                         range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && L.om16[u] != 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = o[e] * L.om16[u];
-                            h[e] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-                            l[e] = (_Float16)fminf(fmaxf((v - (float)h[e]) * p.out_lscale, -65504.f), 65504.f);
+                            _Float16 hh, ll;
+                            split_f16(o[e] * L.om16[u], p.out_lscale, hh, ll);
+                            h[e] = hh;
+                            l[e] = ll;
                         }
                         if (p.half16) {
                             *reinterpret_cast<f16x4*>(p.out16 + (size_t)L.orow[u] * p.ld16 + nc) = h;
@@ -266,5 +267,271 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same epilogue with EIGHT columns per lane (8 lanes per row, 8 rows per pass): every P16 / H16 image store and residual
+// load is 16 bytes per lane instead of 8, fp32 rows go as two 16-byte stores.  An epilogue of 8-byte stores is store-ISSUE
+// bound (MI355X_MICROARCH.md, epilogue store tail; profiles/r02_kstamp.log: 11.8k cycles of a 29k-cycle workgroup for the
+// attention out-projection's 64 x 128 tile): half the passes, half the store and load instructions.  N % 4 == 0 as before; the
+// second half of a lane's columns has its own validity (N = 100).  Used by gemm_p16.hip; gemm_f32.hip keeps the 4-column form.
+template <int BM, bool LN, bool GN = false>
+__device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
+                                                    int M, int m0, int n0, int wm, int wn, int lane, const float* __restrict__ gstat = nullptr) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+    constexpr int NIT = BM / 16;                             // passes: 8 rows per pass
+    const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+    const int co = lane & 7, rg = lane >> 3;
+    const int nc = n0 + wn * 64 + co * 8;                   // first of this lane's 8 columns
+    const bool ok_a = nc < p.N, ok_b = nc + 4 < p.N;        // halves [nc, nc+4) and [nc+4, nc+8)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias[2] = {zero4, zero4}, s0[2] = {zero4, zero4}, s1[2] = {zero4, zero4}, ws[2] = {zero4, zero4};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 0 ? ok_a : ok_b) {
+            if (p.bias) bias[h] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4 * h);
+            if (p.act == ACT_SNAKE) { s0[h] = *reinterpret_cast<const f32x4*>(p.p0 + nc + 4 * h); s1[h] = *reinterpret_cast<const f32x4*>(p.p1 + nc + 4 * h); }
+            if (LN) ws[h] = *reinterpret_cast<const f32x4*>(p.wsum + nc + 4 * h);
+        }
+    }
+    auto sum4 = [](const f32x4& a) { return (a[0] + a[1]) + (a[2] + a[3]); };
+    auto sq4 = [](const f32x4& d) { return (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); };
+    // ---- GroupNorm statistics (see gemm_epilogue_rows): per wave tile, utterance part and group slice; a lane's 8 columns lie in
+    // one group (channels per group % 8 == 0)
+    const bool gn = GN && p.gn_stats != nullptr;
+    int gn_gi = 0, gn_cols0 = 64, gn_bnd = BM, gn_cnt0 = 0, gn_cnt1 = 0;
+    float gn_mean[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gn_mu0 = 0.f, gn_mu1 = 0.f, gn_q0 = 0.f, gn_q1 = 0.f;
+    if constexpr (GN) if (gn) {
+        constexpr int rows_w = BM / 2;
+        const int row_w0 = m0 + wm * rows_w;
+        const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
+        gn_cols0 = min(64, (g0 + 1) * cpg - n0w);
+        gn_gi = (nc / cpg) - g0;
+        if (row_w0 < M) {
+            const int b0 = row_w0 / p.T_out, t_w0 = row_w0 - b0 * p.T_out;
+            const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
+            const int nr1 = (b0 + 1 < p.B) ? (p.gn_nrows ? min(p.T_out, p.gn_nrows[b0 + 1]) : p.T_out) : 0;
+            gn_bnd = min(rows_w, p.T_out - t_w0);
+            gn_cnt0 = max(0, min(gn_bnd, nr0 - t_w0));
+            gn_cnt1 = max(0, min(rows_w - gn_bnd, nr1));
+        }
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rl = it * 8 + rg;
+            const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
+            if (in0 || in1) {
+                const float* q = Cw + rl * GEMM_CS + co * 8;
+                const float t = sum4(*reinterpret_cast<const f32x4*>(q) + bias[0]) + sum4(*reinterpret_cast<const f32x4*>(q + 4) + bias[1]);
+                if (in0) t0 += t; else t1 += t;
+            }
+        }
+        const float c0f = (float)gn_cols0, c1f = (float)(64 - gn_cols0);
+        const float t00 = allreduce64(gn_gi == 0 ? t0 : 0.f), t01 = allreduce64(gn_gi == 1 ? t0 : 0.f);
+        gn_mean[0][0] = gn_cnt0 > 0 ? t00 / ((float)gn_cnt0 * c0f) : 0.f;
+        gn_mean[0][1] = (gn_cnt0 > 0 && gn_cols0 < 64) ? t01 / ((float)gn_cnt0 * c1f) : 0.f;
+        if (gn_cnt1 > 0) {
+            const float t10 = allreduce64(gn_gi == 0 ? t1 : 0.f), t11 = allreduce64(gn_gi == 1 ? t1 : 0.f);
+            gn_mean[1][0] = t10 / ((float)gn_cnt1 * c0f);
+            gn_mean[1][1] = gn_cols0 < 64 ? t11 / ((float)gn_cnt1 * c1f) : 0.f;
+        }
+        gn_mu0 = gn_gi == 0 ? gn_mean[0][0] : gn_mean[0][1];
+        gn_mu1 = gn_gi == 0 ? gn_mean[1][0] : gn_mean[1][1];
+    }
+    bool range_bad = false;
+    float gnr_mu = 0.f, gnr_rs = 1.f, gnr_mu1 = 0.f, gnr_rs1 = 1.f;
+    int gnr_bnd = 0x7fffffff;
+    f32x4 gnr_gm[2] = {zero4, zero4}, gnr_bt[2] = {zero4, zero4};
+    if (p.gnr_y && ok_a) {
+        const int cpg = p.N / p.gnr_groups, gl = nc / cpg - n0 / cpg;
+        gnr_mu = gstat[gl];
+        gnr_rs = gstat[4 + gl];
+        gnr_mu1 = gstat[8 + gl];
+        gnr_rs1 = gstat[12 + gl];
+        gnr_bnd = (m0 / p.T_out + 1) * p.T_out;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            gnr_gm[h] = *reinterpret_cast<const f32x4*>(p.gnr_gamma + nc + 4 * h);
+            gnr_bt[h] = *reinterpret_cast<const f32x4*>(p.gnr_beta + nc + 4 * h);
+        }
+    }
+    auto run = [&](auto act_c, auto res_c) {
+        constexpr int ACT = decltype(act_c)::value;          // 0 none, 1 snake, 2 anything else (runtime switch)
+        constexpr int RESK = decltype(res_c)::value;         // 0 none, 1 fp32 rows, 2 a P16 / H16 image, 3 Block1D tail
+        constexpr int U = 2;                                 // passes per chunk: 16 rows, all their loads in flight together
+        struct ChunkLoads {
+            int orow[U];
+            bool ok[U];
+            float om[U], om16[U], gmk[U];
+            f32x4 rres[U][2];
+            f16x8 r16h[U], r16l[U];
+        };
+        auto load_chunk = [&](int c0, ChunkLoads& L) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + wm * (BM / 2) + (c0 + u) * 8 + rg;
+                L.ok[u] = m < M;
+                const int mc = m < M ? m : M - 1;
+                int r = mc;
+                if (!plain_rows) {
+                    const int b = mc / p.T_out;
+                    r = b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
+                }
+                L.orow[u] = r;
+                L.om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
+                L.om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
+                const int ncl = ok_a ? nc : 0, ncb = ok_b ? nc + 4 : 0;
+                if constexpr (RESK == 1) {
+                    L.rres[u][0] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + ncl);
+                    L.rres[u][1] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + ncb);
+                }
+                if constexpr (RESK == 3) {
+                    L.rres[u][0] = *reinterpret_cast<const f32x4*>(p.gnr_y + (size_t)r * p.N + ncl);
+                    L.rres[u][1] = *reinterpret_cast<const f32x4*>(p.gnr_y + (size_t)r * p.N + ncb);
+                    L.gmk[u] = p.gnr_mask[r];
+                }
+                if constexpr (RESK == 2) {                   // N % 32 == 0 here: both halves valid together
+                    if (p.half16) {
+                        L.r16h[u] = *reinterpret_cast<const f16x8*>(p.res16 + (size_t)r * p.ldr16 + ncl);
+                        L.r16l[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    } else {
+                        const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
+                        L.r16h[u] = *reinterpret_cast<const f16x8*>(q);
+                        L.r16l[u] = *reinterpret_cast<const f16x8*>(q + 32);
+                    }
+                }
+            }
+        };
+        auto process_chunk = [&](int c0, const ChunkLoads& L) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = (c0 + u) * 8 + rg;
+                const float* q = Cw + rl * GEMM_CS + co * 8;
+                f32x4 o[2] = {*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4)};
+                if constexpr (LN) {
+                    const float mean = srow[wm * (BM / 2) + rl], rstd = srow[BM + wm * (BM / 2) + rl];
+                    o[0] = (o[0] - mean * ws[0]) * rstd + bias[0];
+                    o[1] = (o[1] - mean * ws[1]) * rstd + bias[1];
+                } else {
+                    o[0] += bias[0];
+                    o[1] += bias[1];
+                }
+                if (GN && gn) {
+                    const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
+                    if (in0 || in1) {
+                        const float mu = in0 ? gn_mu0 : gn_mu1;
+                        const float t = sq4(o[0] - mu) + sq4(o[1] - mu);
+                        if (in0) gn_q0 += t; else gn_q1 += t;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if constexpr (ACT == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[h][e] = o[h][e] + s1[h][e] * sin_sq(o[h][e] * s0[h][e]);     // SnakeBeta
+                    } else if constexpr (ACT == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[h][e] = act_apply(o[h][e], p.act, s0[h][e], s1[h][e]);
+                    }
+                    o[h] *= L.om[u];
+                    if (p.out_scale != 1.0f) o[h] *= p.out_scale;
+                    if constexpr (RESK == 1) o[h] += L.rres[u][h];
+                    if constexpr (RESK == 3) {       // Mish(GroupNorm(y)) * mask, same operation order as gn_apply_kernel
+                        const bool second = L.orow[u] >= gnr_bnd;
+                        f32x4 v = ((L.rres[u][h] - (second ? gnr_mu1 : gnr_mu)) * (second ? gnr_rs1 : gnr_rs)) * gnr_gm[h] + gnr_bt[h];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = mish_f(v[e]) * L.gmk[u];
+                        o[h] += v;
+                    }
+                    if constexpr (RESK == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[h][e] += (float)L.r16h[u][4 * h + e] + (float)L.r16l[u][4 * h + e] * (1.0f / F16_RES_SCALE);
+                    }
+                }
+                if (L.ok[u]) {
+                    if (p.out) {
+                        float* dst = p.out + (size_t)L.orow[u] * p.ldc + nc;
+                        if (ok_a) *reinterpret_cast<f32x4*>(dst) = o[0];
+                        if (ok_b) *reinterpret_cast<f32x4*>(dst + 4) = o[1];
+                    }
+                    if (p.out16 && ok_a) {                   // (N % 32 == 0 with an image: both halves valid) 8 lanes = one 128-B line
+                        f16x8 hv, lv;
+                        range_bad |= (out_of_f16_range(o[0][0], o[0][1], o[0][2], o[0][3]) || out_of_f16_range(o[1][0], o[1][1], o[1][2], o[1][3])) &&
+                                     L.om16[u] != 0.f;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                _Float16 hh, ll;
+                                split_f16(o[h][e] * L.om16[u], p.out_lscale, hh, ll);
+                                hv[4 * h + e] = hh;
+                                lv[4 * h + e] = ll;
+                            }
+                        if (p.half16) {
+                            *reinterpret_cast<f16x8*>(p.out16 + (size_t)L.orow[u] * p.ld16 + nc) = hv;
+                        } else {
+                            _Float16* o16 = p.out16 + (size_t)L.orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
+                            *reinterpret_cast<f16x8*>(o16) = hv;
+                            *reinterpret_cast<f16x8*>(o16 + 32) = lv;
+                        }
+                    }
+                }
+                if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 8 lanes of the row hold them
+                    const float mu = allreduce8(sum4(o[0]) + sum4(o[1])) * (1.0f / 64.0f);
+                    const float m2 = allreduce8(sq4(o[0] - mu) + sq4(o[1] - mu));
+                    if (co == 0 && L.ok[u]) {
+                        float* so = p.stats_out + ((size_t)L.orow[u] * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                        so[0] = mu;
+                        so[1] = m2;
+                    }
+                }
+            }
+        };
+        ChunkLoads LA, LB;
+        load_chunk(0, LA);
+#pragma unroll
+        for (int c0 = 0; c0 < NIT; c0 += 2 * U) {
+            if (c0 + U < NIT) load_chunk(c0 + U, LB);
+            process_chunk(c0, LA);
+            if (c0 + 2 * U < NIT) load_chunk(c0 + 2 * U, LA);
+            if (c0 + U < NIT) process_chunk(c0 + U, LB);
+        }
+    };
+    const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
+    if (p.gnr_y) {
+        run(IntC<0>{}, IntC<3>{});
+    } else if (p.res16) {
+        if (actk == 0) run(IntC<0>{}, IntC<2>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<2>{});
+        else run(IntC<2>{}, IntC<2>{});
+    } else if (p.res) {
+        if (actk == 0) run(IntC<0>{}, IntC<1>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<1>{});
+        else run(IntC<2>{}, IntC<1>{});
+    } else {
+        if (actk == 0) run(IntC<0>{}, IntC<0>{});
+        else if (actk == 1) run(IntC<1>{}, IntC<0>{});
+        else run(IntC<2>{}, IntC<0>{});
+    }
+    raise_range_flag(p.range_flag, range_bad);
+    if constexpr (GN) if (gn) {
+        const int row_w0 = m0 + wm * (BM / 2), col_wave = (n0 + wn * 64) >> 6;
+        const float q00 = allreduce64(gn_gi == 0 ? gn_q0 : 0.f), q01 = allreduce64(gn_gi == 1 ? gn_q0 : 0.f);
+        float q10 = 0.f, q11 = 0.f;
+        if (gn_cnt1 > 0) { q10 = allreduce64(gn_gi == 0 ? gn_q1 : 0.f); q11 = allreduce64(gn_gi == 1 ? gn_q1 : 0.f); }
+        if (lane == 0 && row_w0 < M) {
+            const int tile = row_w0 / (BM / 2);
+            float* e = p.gn_stats + ((size_t)((tile * 2) * (p.N >> 6) + col_wave) * 2) * 4;
+            *reinterpret_cast<f32x4*>(e) = f32x4{(float)(gn_cnt0 * gn_cols0), gn_mean[0][0], q00, 0.f};
+            *reinterpret_cast<f32x4*>(e + 4) = f32x4{(float)(gn_cnt0 * (64 - gn_cols0)), gn_mean[0][1], q01, 0.f};
+            float* e1 = e + (size_t)(p.N >> 6) * 8;
+            *reinterpret_cast<f32x4*>(e1) = f32x4{(float)(gn_cnt1 * gn_cols0), gn_mean[1][0], q10, 0.f};
+            *reinterpret_cast<f32x4*>(e1 + 4) = f32x4{(float)(gn_cnt1 * (64 - gn_cols0)), gn_mean[1][1], q11, 0.f};
+        }
+    }
+}
+
 
 }  // namespace mtts

@@ -21,7 +21,20 @@
 #include "gemm_epilogue.h"
 #include <cstdlib>
 
+#ifdef MTTS_KSTAMP
+#define MTTS_STAMP(i) do { if (p.kstamp && threadIdx.x == 0) p.kstamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MTTS_STAMP_RT(i) do { if (p.kstamp && threadIdx.x == 0) p.kstamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MTTS_STAMP(i) do { } while (0)
+#define MTTS_STAMP_RT(i) do { } while (0)
+#endif
+
 namespace mtts {
+
+#ifdef MTTS_KSTAMP
+static unsigned long long* g_kstamp = nullptr;            // diagnostic build: where the next launches put their stamps
+extern "C" void mtts_debug_set_kstamp(unsigned long long* p) { g_kstamp = p; }
+#endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -317,12 +330,15 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
             }
         }
     };
+    MTTS_STAMP(0);
+    MTTS_STAMP_RT(4);
     setup_run();
     if constexpr (NST == 2) {
         issue(0);
         ln_stats();
         gnr_prologue();
         __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
+        MTTS_STAMP(1);
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nk) issue(buf ^ 1);   // the other buffer was last read before the barrier that ended step kt-1
@@ -342,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
             // stage may be refilled.  Raw s_barrier: __syncthreads() would wait for every DMA in flight.
             if (kt + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt == 0) MTTS_STAMP(1);
             if (kt + D < nk) issue(st + D >= NST ? st + D - NST : st + D);
             compute(lds + st * STAGE);
             st = st + 1 == NST ? 0 : st + 1;
@@ -349,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         __syncthreads();                       // the epilogue tile overlays the stages: everyone is done reading
     }
 
+    MTTS_STAMP(2);
     // ---- epilogue: park the wave's tile in LDS, re-read it as rows of float4 (16 lanes per row)
     float* Cw = reinterpret_cast<float*>(lds) + wave * ((BM / 2) * P16_CS);
     if constexpr (M16) {
@@ -371,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
     __builtin_amdgcn_wave_barrier();
 
-    gemm_epilogue_rows<BM, LN, GN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);     // (gstat shares srow's slot: never both)
+    gemm_epilogue_rows8<BM, LN, GN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);    // (gstat shares srow's slot: never both)
+    MTTS_STAMP(3);
+    MTTS_STAMP_RT(5);
 }
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
@@ -460,16 +480,19 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     if (a.gn_stats && a.fast16) return hipErrorInvalidValue;          // (the opt-in fp16 mode keeps the separate statistics pass)
     if (a.gn_stats) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
-        if (a.gn_groups <= 0 || (a.N % a.gn_groups) || (a.N / a.gn_groups) < 32 || ((a.N / a.gn_groups) & 3) || (a.N & 63) || !plain ||
+        if (a.gn_groups <= 0 || (a.N % a.gn_groups) || (a.N / a.gn_groups) < 32 || ((a.N / a.gn_groups) & 7) || (a.N & 63) || !plain ||
             a.T_out < gemm_p16_wave_rows(a) || a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f || ln)
             return hipErrorInvalidValue;
     }
     int nst = 2;
     const int bm = p16_choose(a, nst);
+#ifdef MTTS_KSTAMP
+    if (g_kstamp) { GemmArgs b = a; b.kstamp = g_kstamp; g_kstamp = nullptr; return launch_gemm_p16(b, s); }     // one launch per set call
+#endif
     if (a.gnr_y) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
         if (!a.gnr_stats || !a.gnr_gamma || !a.gnr_beta || !a.gnr_mask || a.gnr_groups <= 0 || a.gnr_tile_rows <= 0 || (a.N % a.gnr_groups) ||
-            (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 3) || (a.N & 63) || !plain || a.T_out < bm || a.T_out < a.gnr_tile_rows || ln ||
+            (a.N / a.gnr_groups) < 32 || ((a.N / a.gnr_groups) & 7) || (a.N & 63) || !plain || a.T_out < bm || a.T_out < a.gnr_tile_rows || ln ||
             ((a.gnr_nextra != nullptr) != (a.gnr_bias_stats != nullptr)) ||
             a.act != ACT_NONE || a.res || a.res16 || a.out_mask || a.out_scale != 1.0f)
             return hipErrorInvalidValue;
@@ -497,8 +520,10 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
         f16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            h[e] = (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f);
-            l[e] = (_Float16)fminf(fmaxf((v[e] - (float)h[e]) * lscale, -65504.f), 65504.f);
+            _Float16 a, b;
+            split_f16(v[e], lscale, a, b);
+            h[e] = a;
+            l[e] = b;
         }
         if (half16) {
             *reinterpret_cast<f16x4*>(out + (size_t)row * ld16 + c) = h;

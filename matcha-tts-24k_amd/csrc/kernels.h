@@ -96,6 +96,9 @@ struct GemmArgs {
     // fp16-split arithmetic only: set to 1 (sticky, atomicOr) when an operand this launch splits -- an A element while staging
     // (gemm_f32.hip, terms 2) or an out16 element (epilogue) -- lies beyond +-65504 and saturates.  Null = no check.
     unsigned int* range_flag = nullptr;
+    // diagnostic builds only (-DMTTS_KSTAMP, tools/kstamp.py): per workgroup 8 words = s_memtime at kernel start, first tile
+    // landed, loop end, epilogue end, then s_memrealtime at start and end.  No output value depends on them.
+    unsigned long long* kstamp = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set

@@ -783,7 +783,7 @@ static int decoder_eval(mtts_ctx* c, DecBufs& d, const float* xin, int ev, const
 // MTTS_GN_FUSE=0 keeps the separate pass (A/B runs).  Returns the wave-tile height (the consumers' tile_rows) or 0.
 static int gn_fuse_rows(const GemmArgs& a, int C, int G, int T) {
     static const bool on = [] { const char* e = getenv("MTTS_GN_FUSE"); return !(e && e[0] == '0'); }();
-    if (!on || !a.a16_0 || a.fast16 || (C % 64) || (C % G) || (C / G) < 32 || ((C / G) & 3)) return 0;
+    if (!on || !a.a16_0 || a.fast16 || (C % 64) || (C % G) || (C / G) < 32 || ((C / G) & 7)) return 0;
     const int rows = gemm_p16_wave_rows(a);
     return T >= rows ? rows : 0;
 }

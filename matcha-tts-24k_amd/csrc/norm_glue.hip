@@ -352,9 +352,10 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
                 range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && m16[u] != 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float w = o[e] * m16[u];
-                    hh[e] = (_Float16)fminf(fmaxf(w, -65504.f), 65504.f);
-                    ll[e] = (_Float16)fminf(fmaxf((w - (float)hh[e]) * 2048.0f, -65504.f), 65504.f);
+                    _Float16 a, b;
+                    split_f16(o[e] * m16[u], a, b);
+                    hh[e] = a;
+                    ll[e] = b;
                 }
                 if (p.half16) {
                     *reinterpret_cast<f16x4*>(p.out16 + row[u] * (size_t)p.ld16 + c4 * 4) = hh;

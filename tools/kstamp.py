@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""In-kernel stamps of the P16 GEMM (diagnostic build, -DMTTS_KSTAMP): where a workgroup's lifetime goes.
+  build (CPU box):  python tools/kstamp.py --build          -> tools/ab/kstamp.so (gemm_p16.hip recompiled with the stamps)
+  run (GPU box):    MTTS_HIP_LIB=$PWD/tools/ab/kstamp.so python tools/kstamp.py
+Per shape: median cycles from kernel start to the first tile landed, per k-step of the main loop, of the epilogue; the
+workgroup lifetime and the launch span in microseconds; the in-kernel clock (s_memtime / s_memrealtime)."""
+import argparse
+import ctypes as C
+import importlib
+import os
+import statistics
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+PKG = "matcha-tts-24k_amd"
+
+
+def build():
+    pk = ROOT / PKG
+    obj = "/tmp/gemm_p16_kstamp.o"
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+           "-DMTTS_KSTAMP", "-c", str(pk / "csrc" / "gemm_p16.hip"), "-o", obj]
+    subprocess.run(cmd, check=True)
+    others = [str(pk / "build" / f"{n}.o") for n in ("gemm_f32", "attention_f32", "norm_glue", "vocos", "model")]
+    out = ROOT / "tools" / "ab" / "kstamp.so"
+    out.parent.mkdir(exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", str(out)], check=True)
+    print("built", out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--batch", type=int, default=32)
+    args = ap.parse_args()
+    if args.build:
+        return build()
+    import torch
+    hip = importlib.import_module(PKG + "._hip")
+    lib = hip.load()
+    lib.mtts_debug_set_kstamp.argtypes = [C.c_void_p]
+    lib.mtts_debug_set_kstamp.restype = None
+    dev = torch.device("cuda")
+    B = args.batch
+    shapes = [  # name, T, C, ntaps, N, kind
+        ("L0 conv k3 384->384", 322, 384, 3, 384, "plain"),
+        ("L0 qkv 384->1152 (LN)", 322, 384, 1, 1152, "ln"),
+        ("L0 out 384->384 (+res, image)", 322, 384, 1, 384, "res"),
+        ("L0 ff1 384->1536 (LN, snake, image)", 322, 384, 1, 1536, "ff1"),
+        ("L0 ff2 1536->384 (+res, image)", 322, 1536, 1, 384, "res"),
+        ("L1 conv k3 384->384", 161, 384, 3, 384, "plain"),
+        ("L1 qkv", 161, 384, 1, 1152, "ln"),
+        ("L1 out", 161, 384, 1, 384, "res"),
+        ("L1 ff1", 161, 384, 1, 1536, "ff1"),
+        ("L1 ff2", 161, 1536, 1, 384, "res"),
+    ]
+    print(f"{'shape':38s} {'WGs':>5s} {'nk':>3s} | {'first tile':>10s} {'cyc/k-step':>10s} {'epilogue':>9s} | {'WG us':>6s} {'span us':>7s} {'GHz':>5s}")
+    for name, T, Cc, nt, N, kind in shapes:
+        a = torch.randn(B * T, Cc, device=dev)
+        w = torch.randn(N, Cc, nt, device=dev) * (Cc * nt) ** -0.5 if nt > 1 else torch.randn(N, Cc, device=dev) * Cc ** -0.5
+        bias = torch.randn(N, device=dev)
+        kw = dict(B=B, T_in=T)
+        if kind in ("ln", "ff1"):
+            kw.update(a_mean=torch.zeros(B * T, device=dev), a_rstd=torch.ones(B * T, device=dev))
+        if kind == "ff1":
+            kw.update(act=3, p0=torch.ones(N, device=dev), p1=torch.ones(N, device=dev), want_f32=False, want_p16=True)
+        if kind == "res":
+            kw.update(res=torch.randn(B * T, N, device=dev), want_p16=True, stats_out=True)
+        stamps = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
+        for rep in range(3):                                   # the last launch is the one read
+            stamps.zero_()
+            lib.mtts_debug_set_kstamp(stamps.data_ptr())
+            hip.gemm_p16(a, w, bias, **kw)
+        torch.cuda.synchronize()
+        s = stamps.cpu().view(-1, 8)
+        live = s[:, 3] != 0
+        s = s[live]
+        nk = nt * Cc // 32
+        first = (s[:, 1] - s[:, 0]).tolist()
+        loop = ((s[:, 2] - s[:, 1]).double() / max(nk - 1, 1)).tolist()       # stamp 1 sits after the first tile's barrier
+        epi = (s[:, 3] - s[:, 2]).tolist()
+        life = (s[:, 3] - s[:, 0]).double()
+        rt = (s[:, 5] - s[:, 4]).double().clamp_min(1)                        # 100 MHz ticks
+        ghz = float((life / rt).median()) * 0.1
+        span_us = float(s[:, 5].max() - s[:, 4].min()) / 100.0
+        med = statistics.median
+        print(f"{name:38s} {len(s):5d} {nk:3d} | {med(first):10.0f} {med(loop):10.0f} {med(epi):9.0f} | "
+              f"{float(life.median()) / (ghz * 1e3):6.1f} {span_us:7.1f} {ghz:5.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
