@@ -13,6 +13,10 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#ifndef MTTS_STAMP
+#define MTTS_STAMP(i) do { } while (0)
+#endif
+
 namespace mtts {
 
 constexpr int GEMM_CS = 68;   // row stride of the parked tile (floats)
@@ -274,27 +278,140 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& p, const floa
 // bound (MI355X_MICROARCH.md, epilogue store tail; profiles/r02_kstamp.log: 11.8k cycles of a 29k-cycle workgroup for the
 // attention out-projection's 64 x 128 tile): half the passes, half the store and load instructions.  N % 4 == 0 as before; the
 // second half of a lane's columns has its own validity (N = 100).  Used by gemm_p16.hip; gemm_f32.hip keeps the 4-column form.
+//
+// What is left after that is vector-instruction issue (profiles/r02_kstamp_sub.log: a 16-row chunk costs 3-4k cycles with two
+// waves per SIMD, ~33 instructions per element in the ISA), so the element path is kept short:
+//   * the residual image is widened by ONE v_fma_mix_f32 per element (h + l / 2^11 is exact in the fma: bit-identical to
+//     cvt, cvt, mul, add);
+//   * the fp16 split packs h with v_cvt_pk_f16_f32 and takes the residual c - h as a v_fma_mix_f32 on the packed register (no
+//     second conversion, no unpack); l = (r * lscale) rounds once more to fp16 as before (v_fma_mixlo/hi_f16);
+//   * the range guard keeps a running v_max3_f32 of |value after the image mask| (4 instructions per 8 elements, one compare
+//     per workgroup at the end; a masked row cannot raise it: inf * 0 = NaN, which max3 drops, as `om16 != 0` did);
+//   * out_mask and out_scale are one factor (the mask is 0 or 1: (c * m) * s == c * (m * s) bit for bit);
+//   * the kernel arguments the passes need sit in SGPRs (pinned once; the compiler otherwise re-loads them from the kernarg
+//     segment inside each pass, an s_load + s_waitcnt per use).
+// The column constants (bias, SnakeBeta, panel sums) and -- for 64-row tiles -- the whole residual image tile are requested
+// BEFORE the k-loop (EpiPre / epi_prefetch), so their round trip to L2 / HBM hides under it instead of opening the epilogue.
+using f32x4_e = __attribute__((ext_vector_type(4))) float;
+using f16x8_e = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2_e = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4_e = __attribute__((ext_vector_type(4))) unsigned int;
+
+struct EpiCols {                                             // a lane's 8 columns: [nc, nc+4) and [nc+4, nc+8)
+    f32x4_e bias[2], s0[2], s1[2], ws[2];
+};
+template <int BM>
+struct EpiPre {                                              // residual image rows of a 64-row tile (4 passes), else unused
+    static constexpr int N = BM == 64 ? 4 : 1;
+    f16x8_e h[N], l[N];
+    bool valid;
+};
+
+template <bool LN>
+__device__ __forceinline__ EpiCols epi_load_cols(const GemmArgs& p, int n0, int wn, int lane) {
+    const f32x4_e zero4 = {0.f, 0.f, 0.f, 0.f};
+    EpiCols c;
+    const int nc = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        c.bias[h] = zero4; c.s0[h] = zero4; c.s1[h] = zero4; c.ws[h] = zero4;
+        if (nc + 4 * h < p.N) {
+            if (p.bias) c.bias[h] = *reinterpret_cast<const f32x4_e*>(p.bias + nc + 4 * h);
+            if (p.act == ACT_SNAKE) { c.s0[h] = *reinterpret_cast<const f32x4_e*>(p.p0 + nc + 4 * h); c.s1[h] = *reinterpret_cast<const f32x4_e*>(p.p1 + nc + 4 * h); }
+            if (LN) c.ws[h] = *reinterpret_cast<const f32x4_e*>(p.wsum + nc + 4 * h);
+        }
+    }
+    return c;
+}
+
+// output row of tile row m (the epilogue's mapping: plain rows, or strided / offset rows of a longer output)
+__device__ __forceinline__ int epi_out_row(const GemmArgs& p, int m, int M, bool plain_rows) {
+    const int mc = m < M ? m : M - 1;
+    if (plain_rows) return mc;
+    const int b = mc / p.T_out;
+    return b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
+}
+
+template <int BM>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<BM>& pre, int M, int m0, int n0, int wm, int wn, int lane) {
+    pre.valid = false;
+    if constexpr (BM == 64) {
+        if (p.res16 && !p.gnr_y) {                           // (an image implies N % 32 == 0: a lane's 8 columns are valid together)
+            pre.valid = true;
+            const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+            const int nc = n0 + wn * 64 + (lane & 7) * 8, rg = lane >> 3;
+            const int ncl = nc < p.N ? nc : 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = epi_out_row(p, m0 + wm * 32 + it * 8 + rg, M, plain_rows);
+                if (p.half16) {
+                    pre.h[it] = *reinterpret_cast<const f16x8_e*>(p.res16 + (size_t)r * p.ldr16 + ncl);
+                    pre.l[it] = f16x8_e{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
+                    const _Float16* q = p.res16 + (size_t)r * p.ldr16 + (ncl >> 5) * 64 + (ncl & 31);
+                    pre.h[it] = *reinterpret_cast<const f16x8_e*>(q);
+                    pre.l[it] = *reinterpret_cast<const f16x8_e*>(q + 32);
+                }
+            }
+        }
+    }
+}
+
+// h + l / 2^11 of a packed pair of image halves (element 2k and 2k+1 of the 8): one v_fma_mix_f32 each
+__device__ __forceinline__ void widen_pair(unsigned int hpk, unsigned int lpk, float& a, float& b) {
+    const float k = 1.0f / F16_RES_SCALE;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(lpk), "v"(k), "v"(hpk));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(lpk), "v"(k), "v"(hpk));
+}
+// the fp16 split of two values (already multiplied by the image mask): packed h, packed l, running |max| for the range guard
+template <bool WANT_L>
+__device__ __forceinline__ void split_pair(float x0, float x1, float lscale, unsigned int& hpk, unsigned int& lpk, float& rmax) {
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rmax) : "v"(x0), "v"(x1));
+    const float c0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    const f16x2_e hp = {(_Float16)c0, (_Float16)c1};         // v_cvt_pk_f16_f32 (round to nearest even, as the scalar casts)
+    hpk = __builtin_bit_cast(unsigned int, hp);
+    lpk = 0u;
+    if constexpr (WANT_L) {
+        const float neg1 = -1.0f;
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpk), "v"(neg1), "v"(c0));                      // c0 - h0 (exact)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpk), "v"(neg1), "v"(c1));
+        const f16x2_e lp = {(_Float16)(r0 * lscale), (_Float16)(r1 * lscale)};
+        lpk = __builtin_bit_cast(unsigned int, lp);
+    }
+}
+
 template <int BM, bool LN, bool GN = false>
-__device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const float* __restrict__ Cw, const float* __restrict__ srow,
-                                                    int M, int m0, int n0, int wm, int wn, int lane, const float* __restrict__ gstat = nullptr) {
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+__device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const EpiCols& cols, const EpiPre<BM>& pre, const float* __restrict__ Cw,
+                                                    const float* __restrict__ Cw2, const float* __restrict__ srow, int M, int m0, int n0, int wm, int wn, int lane,
+                                                    const float* __restrict__ gstat = nullptr) {
+    using f32x4 = f32x4_e;
+    using f16x8 = f16x8_e;
     constexpr int NIT = BM / 16;                             // passes: 8 rows per pass
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int co = lane & 7, rg = lane >> 3;
     const int nc = n0 + wn * 64 + co * 8;                   // first of this lane's 8 columns
     const bool ok_a = nc < p.N, ok_b = nc + 4 < p.N;        // halves [nc, nc+4) and [nc+4, nc+8)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bias[2] = {zero4, zero4}, s0[2] = {zero4, zero4}, s1[2] = {zero4, zero4}, ws[2] = {zero4, zero4};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h == 0 ? ok_a : ok_b) {
-            if (p.bias) bias[h] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4 * h);
-            if (p.act == ACT_SNAKE) { s0[h] = *reinterpret_cast<const f32x4*>(p.p0 + nc + 4 * h); s1[h] = *reinterpret_cast<const f32x4*>(p.p1 + nc + 4 * h); }
-            if (LN) ws[h] = *reinterpret_cast<const f32x4*>(p.wsum + nc + 4 * h);
-        }
-    }
+    const f32x4 bias[2] = {cols.bias[0], cols.bias[1]}, s0[2] = {cols.s0[0], cols.s0[1]}, s1[2] = {cols.s1[0], cols.s1[1]},
+                ws[2] = {cols.ws[0], cols.ws[1]};
+    // the arguments the passes use, pinned in SGPRs
+    // (the empty asm makes each an SGPR value the compiler cannot re-load; a laundered pointer is generic, so it is cast back
+    // to the global address space: flat stores would also tick lgkmcnt)
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) const float gcfloat;
+    typedef __attribute__((address_space(1))) _Float16 ghalf;
+    unsigned long long q_out = (unsigned long long)p.out, q_out16 = (unsigned long long)p.out16, q_stats = (unsigned long long)p.stats_out,
+                       q_om = (unsigned long long)p.out_mask, q_om16 = (unsigned long long)p.out16_mask;
+    int a_ldc = p.ldc, a_ld16 = p.ld16, a_half = p.half16 ? 1 : 0, a_nw = p.N >> 6;
+    float a_scale = p.out_scale, a_lscale = p.out_lscale;
+    asm volatile("" : "+s"(q_out), "+s"(q_out16), "+s"(q_stats), "+s"(q_om), "+s"(q_om16));
+    asm volatile("" : "+s"(a_ldc), "+s"(a_ld16), "+s"(a_half), "+s"(a_nw), "+s"(a_scale), "+s"(a_lscale));
+    gfloat* const a_out = (gfloat*)q_out;
+    ghalf* const a_out16 = (ghalf*)q_out16;
+    gfloat* const a_stats = (gfloat*)q_stats;
+    gcfloat* const a_om = (gcfloat*)q_om;
+    gcfloat* const a_om16 = (gcfloat*)q_om16;
     auto sum4 = [](const f32x4& a) { return (a[0] + a[1]) + (a[2] + a[3]); };
     auto sq4 = [](const f32x4& d) { return (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); };
     // ---- GroupNorm statistics (see gemm_epilogue_rows): per wave tile, utterance part and group slice; a lane's 8 columns lie in
@@ -323,7 +440,13 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
             const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
             if (in0 || in1) {
                 const float* q = Cw + rl * GEMM_CS + co * 8;
-                const float t = sum4(*reinterpret_cast<const f32x4*>(q) + bias[0]) + sum4(*reinterpret_cast<const f32x4*>(q + 4) + bias[1]);
+                f32x4 qa = *reinterpret_cast<const f32x4*>(q), qb = *reinterpret_cast<const f32x4*>(q + 4);
+                if (Cw2) {
+                    const float* q2 = Cw2 + rl * GEMM_CS + co * 8;
+                    qa += *reinterpret_cast<const f32x4*>(q2);
+                    qb += *reinterpret_cast<const f32x4*>(q2 + 4);
+                }
+                const float t = sum4(qa + bias[0]) + sum4(qb + bias[1]);
                 if (in0) t0 += t; else t1 += t;
             }
         }
@@ -339,7 +462,7 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
         gn_mu0 = gn_gi == 0 ? gn_mean[0][0] : gn_mean[0][1];
         gn_mu1 = gn_gi == 0 ? gn_mean[1][0] : gn_mean[1][1];
     }
-    bool range_bad = false;
+    float rmax = 0.f;                                        // range guard: running max of |value written to an image|
     float gnr_mu = 0.f, gnr_rs = 1.f, gnr_mu1 = 0.f, gnr_rs1 = 1.f;
     int gnr_bnd = 0x7fffffff;
     f32x4 gnr_gm[2] = {zero4, zero4}, gnr_bt[2] = {zero4, zero4};
@@ -367,20 +490,16 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
             f32x4 rres[U][2];
             f16x8 r16h[U], r16l[U];
         };
-        auto load_chunk = [&](int c0, ChunkLoads& L) {
+        auto load_chunk = [&](auto c0_c, ChunkLoads& L) {
+            constexpr int c0 = decltype(c0_c)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int m = m0 + wm * (BM / 2) + (c0 + u) * 8 + rg;
                 L.ok[u] = m < M;
-                const int mc = m < M ? m : M - 1;
-                int r = mc;
-                if (!plain_rows) {
-                    const int b = mc / p.T_out;
-                    r = b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
-                }
+                const int r = epi_out_row(p, m, M, plain_rows);
                 L.orow[u] = r;
-                L.om[u] = p.out_mask ? p.out_mask[r] : 1.0f;
-                L.om16[u] = p.out16_mask ? p.out16_mask[r] : 1.0f;
+                L.om[u] = (a_om ? a_om[r] : 1.0f) * a_scale;    // the mask is 0 or 1: one factor serves both
+                L.om16[u] = a_om16 ? a_om16[r] : 1.0f;
                 const int ncl = ok_a ? nc : 0, ncb = ok_b ? nc + 4 : 0;
                 if constexpr (RESK == 1) {
                     L.rres[u][0] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + ncl);
@@ -392,7 +511,10 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
                     L.gmk[u] = p.gnr_mask[r];
                 }
                 if constexpr (RESK == 2) {                   // N % 32 == 0 here: both halves valid together
-                    if (p.half16) {
+                    if (BM == 64 && pre.valid) {             // requested beside the first tiles (epi_prefetch)
+                        L.r16h[u] = pre.h[BM == 64 ? c0 + u : 0];
+                        L.r16l[u] = pre.l[BM == 64 ? c0 + u : 0];
+                    } else if (a_half) {
                         L.r16h[u] = *reinterpret_cast<const f16x8*>(p.res16 + (size_t)r * p.ldr16 + ncl);
                         L.r16l[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     } else {
@@ -409,6 +531,11 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
                 const int rl = (c0 + u) * 8 + rg;
                 const float* q = Cw + rl * GEMM_CS + co * 8;
                 f32x4 o[2] = {*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4)};
+                if (Cw2) {                                   // split-K: the second wave set's partial sums
+                    const float* q2 = Cw2 + rl * GEMM_CS + co * 8;
+                    o[0] += *reinterpret_cast<const f32x4*>(q2);
+                    o[1] += *reinterpret_cast<const f32x4*>(q2 + 4);
+                }
                 if constexpr (LN) {
                     const float mean = srow[wm * (BM / 2) + rl], rstd = srow[BM + wm * (BM / 2) + rl];
                     o[0] = (o[0] - mean * ws[0]) * rstd + bias[0];
@@ -425,6 +552,11 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
                         if (in0) gn_q0 += t; else gn_q1 += t;
                     }
                 }
+                [[maybe_unused]] u32x4_e rh, rlw;
+                if constexpr (RESK == 2) {
+                    rh = __builtin_bit_cast(u32x4_e, L.r16h[u]);
+                    rlw = __builtin_bit_cast(u32x4_e, L.r16l[u]);
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if constexpr (ACT == 1) {
@@ -435,7 +567,6 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
                         for (int e = 0; e < 4; ++e) o[h][e] = act_apply(o[h][e], p.act, s0[h][e], s1[h][e]);
                     }
                     o[h] *= L.om[u];
-                    if (p.out_scale != 1.0f) o[h] *= p.out_scale;
                     if constexpr (RESK == 1) o[h] += L.rres[u][h];
                     if constexpr (RESK == 3) {       // Mish(GroupNorm(y)) * mask, same operation order as gn_apply_kernel
                         const bool second = L.orow[u] >= gnr_bnd;
@@ -446,43 +577,52 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
                     }
                     if constexpr (RESK == 2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            o[h][e] += (float)L.r16h[u][4 * h + e] + (float)L.r16l[u][4 * h + e] * (1.0f / F16_RES_SCALE);
-                    }
-                }
-                if (L.ok[u]) {
-                    if (p.out) {
-                        float* dst = p.out + (size_t)L.orow[u] * p.ldc + nc;
-                        if (ok_a) *reinterpret_cast<f32x4*>(dst) = o[0];
-                        if (ok_b) *reinterpret_cast<f32x4*>(dst + 4) = o[1];
-                    }
-                    if (p.out16 && ok_a) {                   // (N % 32 == 0 with an image: both halves valid) 8 lanes = one 128-B line
-                        f16x8 hv, lv;
-                        range_bad |= (out_of_f16_range(o[0][0], o[0][1], o[0][2], o[0][3]) || out_of_f16_range(o[1][0], o[1][1], o[1][2], o[1][3])) &&
-                                     L.om16[u] != 0.f;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                _Float16 hh, ll;
-                                split_f16(o[h][e] * L.om16[u], p.out_lscale, hh, ll);
-                                hv[4 * h + e] = hh;
-                                lv[4 * h + e] = ll;
-                            }
-                        if (p.half16) {
-                            *reinterpret_cast<f16x8*>(p.out16 + (size_t)L.orow[u] * p.ld16 + nc) = hv;
-                        } else {
-                            _Float16* o16 = p.out16 + (size_t)L.orow[u] * p.ld16 + (nc >> 5) * 64 + (nc & 31);
-                            *reinterpret_cast<f16x8*>(o16) = hv;
-                            *reinterpret_cast<f16x8*>(o16 + 32) = lv;
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            float ra, rb;
+                            widen_pair(rh[2 * h + e2], rlw[2 * h + e2], ra, rb);
+                            o[h][2 * e2] += ra;
+                            o[h][2 * e2 + 1] += rb;
                         }
                     }
                 }
-                if (p.stats_out) {   // (mean, M2) of this wave's 64 columns of the row: the 8 lanes of the row hold them
+                if (L.ok[u]) {
+                    if (a_out) {
+                        gfloat* dst = a_out + (size_t)L.orow[u] * a_ldc + nc;
+                        if (ok_a) *(__attribute__((address_space(1))) f32x4*)dst = o[0];
+                        if (ok_b) *(__attribute__((address_space(1))) f32x4*)(dst + 4) = o[1];
+                    }
+                    if (a_out16 && ok_a) {                   // (N % 32 == 0 with an image: both halves valid) 8 lanes = one 128-B line
+                        const float m16 = L.om16[u];
+                        if (a_half) {                        // H16: one plane
+                            u32x4_e hv;
+                            unsigned int lp;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                unsigned int hp;
+                                split_pair<false>(o[k >> 1][2 * (k & 1)] * m16, o[k >> 1][2 * (k & 1) + 1] * m16, a_lscale, hp, lp, rmax);
+                                hv[k] = hp;
+                            }
+                            *(__attribute__((address_space(1))) u32x4_e*)(a_out16 + (size_t)L.orow[u] * a_ld16 + nc) = hv;
+                        } else {
+                            u32x4_e hv, lv;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                unsigned int hp, lp;
+                                split_pair<true>(o[k >> 1][2 * (k & 1)] * m16, o[k >> 1][2 * (k & 1) + 1] * m16, a_lscale, hp, lp, rmax);
+                                hv[k] = hp;
+                                lv[k] = lp;
+                            }
+                            ghalf* o16 = a_out16 + (size_t)L.orow[u] * a_ld16 + (nc >> 5) * 64 + (nc & 31);
+                            *(__attribute__((address_space(1))) u32x4_e*)o16 = hv;
+                            *(__attribute__((address_space(1))) u32x4_e*)(o16 + 32) = lv;
+                        }
+                    }
+                }
+                if (a_stats) {   // (mean, M2) of this wave's 64 columns of the row: the 8 lanes of the row hold them
                     const float mu = allreduce8(sum4(o[0]) + sum4(o[1])) * (1.0f / 64.0f);
                     const float m2 = allreduce8(sq4(o[0] - mu) + sq4(o[1] - mu));
                     if (co == 0 && L.ok[u]) {
-                        float* so = p.stats_out + ((size_t)L.orow[u] * (p.N >> 6) + ((n0 + wn * 64) >> 6)) * 2;
+                        gfloat* so = a_stats + ((size_t)L.orow[u] * a_nw + ((n0 + wn * 64) >> 6)) * 2;
                         so[0] = mu;
                         so[1] = m2;
                     }
@@ -490,13 +630,16 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
             }
         };
         ChunkLoads LA, LB;
-        load_chunk(0, LA);
-#pragma unroll
-        for (int c0 = 0; c0 < NIT; c0 += 2 * U) {
-            if (c0 + U < NIT) load_chunk(c0 + U, LB);
-            process_chunk(c0, LA);
-            if (c0 + 2 * U < NIT) load_chunk(c0 + 2 * U, LA);
-            if (c0 + U < NIT) process_chunk(c0 + U, LB);
+        load_chunk(IntC<0>{}, LA);
+        if constexpr (NIT > U) load_chunk(IntC<U>{}, LB);
+        process_chunk(0, LA);
+        MTTS_STAMP(7);
+        if constexpr (NIT > 2 * U) load_chunk(IntC<2 * U>{}, LA);
+        if constexpr (NIT > U) process_chunk(U, LB);
+        if constexpr (NIT > 2 * U) {
+            load_chunk(IntC<3 * U>{}, LB);
+            process_chunk(2 * U, LA);
+            process_chunk(3 * U, LB);
         }
     };
     const int actk = p.act == ACT_NONE ? 0 : (p.act == ACT_SNAKE ? 1 : 2);     // wave-uniform dispatch
@@ -515,7 +658,7 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const flo
         else if (actk == 1) run(IntC<1>{}, IntC<0>{});
         else run(IntC<2>{}, IntC<0>{});
     }
-    raise_range_flag(p.range_flag, range_bad);
+    raise_range_flag(p.range_flag, rmax > 65504.f);
     if constexpr (GN) if (gn) {
         const int row_w0 = m0 + wm * (BM / 2), col_wave = (n0 + wn * 64) >> 6;
         const float q00 = allreduce64(gn_gi == 0 ? gn_q0 : 0.f), q01 = allreduce64(gn_gi == 1 ? gn_q0 : 0.f);

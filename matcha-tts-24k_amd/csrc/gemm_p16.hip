@@ -18,9 +18,6 @@
 // Replaces, like gemm_f32.hip: nn.Linear / nn.Conv1d of the reference decoder (decoder.py, transformer.py) on the hot path.
 #include "kernels.h"
 #include "device_utils.h"
-#include "gemm_epilogue.h"
-#include <cstdlib>
-
 #ifdef MTTS_KSTAMP
 #define MTTS_STAMP(i) do { if (p.kstamp && threadIdx.x == 0) p.kstamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MTTS_STAMP_RT(i) do { if (p.kstamp && threadIdx.x == 0) p.kstamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -28,6 +25,9 @@
 #define MTTS_STAMP(i) do { } while (0)
 #define MTTS_STAMP_RT(i) do { } while (0)
 #endif
+#include "gemm_epilogue.h"
+#include <cstdlib>
+
 
 namespace mtts {
 
@@ -46,8 +46,10 @@ __device__ __attribute__((aligned(128))) _Float16 g_p16_zero_line[64];     // so
 constexpr int P16_CS = GEMM_CS;                                             // epilogue tile row stride (floats)
 constexpr int p16_stage_bytes(int BM) { return (BM + GEMM_BN) * 128; }
 constexpr int p16_epi_bytes(int BM) { return 4 * (BM / 2) * P16_CS * 4; }
-constexpr int p16_main_bytes(int BM, int NST) { return NST * p16_stage_bytes(BM) > p16_epi_bytes(BM) ? NST * p16_stage_bytes(BM) : p16_epi_bytes(BM); }
-constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 2 * BM * 4; }   // + per-row (mean, rstd)
+constexpr int p16_main_bytes(int BM, int NST, int KS = 1) {
+    return KS * NST * p16_stage_bytes(BM) > KS * p16_epi_bytes(BM) ? KS * NST * p16_stage_bytes(BM) : KS * p16_epi_bytes(BM);
+}
+constexpr int p16_lds_bytes(int BM, int NST, int KS = 1) { return p16_main_bytes(BM, NST, KS) + 2 * BM * 4; }   // + per-row (mean, rstd)
 
 #define MTTS_GLDS16(gp, lp) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
@@ -62,8 +64,14 @@ constexpr int p16_lds_bytes(int BM, int NST) { return p16_main_bytes(BM, NST) + 
 // MODE: 0 = P16 operands, three products per MAC (the default, fp32-equivalent); 1 = P16 operands, heads x heads only (the
 // opt-in fp16 mode, ONE); 2 = H16 operands (GemmArgs::half16): a 128-byte line holds 64 k of one fp16 plane, a k-step is 64
 // deep and its two 32-k halves are what the head / residual chunks of a P16 line are to the DMA and the fragment reads.
-template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false>
-__global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
+// KS: intra-workgroup split-K.  A grid of at most one workgroup per CU (B = 32 at the half-length level, every serving shape)
+// leaves one wave per SIMD, and a k-step then costs the wave's own serial chain (fragment reads -> MFMAs -> DMA issue, ~1.05k
+// cycles for 384 cycles of MFMA: profiles/r02_kstamp.log).  With KS = 2 the workgroup has 8 waves: waves 0-3 run the first half
+// of the K axis, waves 4-7 the second half, each set on its own ring of LDS stages -- two waves per SIMD hide each other's
+// chains exactly as two co-resident workgroups do, without needing a second tile.  Both sets park their partial tiles; waves
+// 0-3 add them in the epilogue (fp32; the order of the two partial sums is fixed, so results are run-to-run identical).
+template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(const GemmArgs p) {
     static_assert(!(GN && LN), "GroupNorm statistics come from conv GEMMs, which have no LayerNorm prologue");
     constexpr bool ONE = MODE == 1;
     constexpr bool HALF = MODE == 2;
@@ -71,9 +79,12 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
     constexpr int STAGE = p16_stage_bytes(BM);
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE array: stages | epilogue tile | row statistics
-    float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM, NST));
+    float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM, NST, KS));
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid_all = threadIdx.x;
+    const int ks = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid_all >> 8);      // which part of the K axis (wave-uniform)
+    const int tid = tid_all & 255, lane = tid & 63, wave = tid >> 6;                // position inside the 4-wave set
+    char* const lds_k = lds + ks * (NST * STAGE);                                   // this set's ring
     const int wm = wave >> 1, wn = wave & 1;
     const int M = p.B * p.T_out;
     const int Kp = p.ntaps * p.ktap;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         run_left = (seg1 ? p.c1 : p.c0) / KSTEP;
     };
     auto issue = [&](int buf) {
-        char* st = lds + buf * STAGE;
+        char* st = lds_k + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
             MTTS_GLDS16(asrc[j], st + (wave * APW + j) * 1024);
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
 
     // operand fragment: lane (r = lane&15, q = lane>>4) holds k = 8q .. 8q+7 of row r -- head chunk q, residual chunk 4 + q
     const int fr = lane & 15, fq = lane >> 4, f8 = (fr >> 1) & 7;
-    const int nk = Kp / KSTEP;
+    const int nk = Kp / KSTEP / KS;                        // k-steps of this set (the host checks divisibility)
     auto compute16 = [&](const char* stage) {
         const char* sa = stage + (wm * (BM / 2) + fr) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
@@ -236,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     // first tile requests so that their loads overlap the tiles' flight
     auto ln_stats = [&]() {
         if (LN) {
-            if (tid < BM) {
-                const int row = min(m0 + tid, M - 1);
+            if (tid_all < BM) {
+                const int row = min(m0 + tid_all, M - 1);
                 float mean, rstd;
                 if (p.a_part) {
                     const float* q = p.a_part + (size_t)row * p.a_nparts * 2;
@@ -261,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                     mean = p.a_mean[row];
                     rstd = p.a_rstd[row];
                 }
-                srow[tid] = mean;
-                srow[BM + tid] = rstd;
+                srow[tid_all] = mean;
+                srow[BM + tid_all] = rstd;
             }
         }
     };
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     // columns (16 lanes per group, Chan merge, fixed order) into gstat = [mean x 4 | rstd x 4], parked where srow would be.
     // A workgroup's rows lie in at most two utterances (T_out >= BM): wave 0 merges for the first, wave 1 for the second.
     auto gnr_prologue = [&]() {
-        if (p.gnr_y && tid < 128) {
+        if (p.gnr_y && tid_all < 128) {
             const int cpg = p.N / p.gnr_groups, gl = (tid & 63) >> 4, j = tid & 15, g = n0 / cpg + gl;
             const int b = m0 / p.T_out + (tid >> 6);
             const bool live = g < p.gnr_groups && g * cpg < min(p.N, n0 + GEMM_BN) && b < p.B;
@@ -332,9 +343,42 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
     };
     MTTS_STAMP(0);
     MTTS_STAMP_RT(4);
-    setup_run();
+    // epilogue operands whose round trip should hide under the k-loop: the residual image tile (64-row tiles) and, where the
+    // register budget allows (64-row tiles again), the column constants; requested BEFORE the first tiles so that they are the
+    // oldest entries of the vector-memory counter and the ring's counted waits stay exact
+    EpiPre<BM> pre;
+    pre.valid = false;
+#ifndef MTTS_EPI_PRE
+#define MTTS_EPI_PRE 2
+#endif
+#if MTTS_EPI_PRE == 1
+    if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+#endif
+    EpiCols cols;
+    if constexpr (BM == 64) { if (ks == 0) cols = epi_load_cols<LN>(p, n0, wn, lane); }
+    if constexpr (KS > 1) {                     // this set's first k-step: walk the runs (tap, segment) up to step ks * nk
+        int skip = ks * nk;
+        for (;;) {
+            const int len = (run_seg == 1 ? p.c1 : p.c0) / KSTEP;
+            if (skip < len) break;
+            skip -= len;
+            if (run_seg == 0 && p.a16_1 != nullptr) run_seg = 1;
+            else { run_seg = 0; ++run_tap; }
+        }
+        setup_run();
+#pragma unroll
+        for (int j = 0; j < APW; ++j) asrc[j] += skip * astep[j];
+        run_left -= skip;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wsrc[j] += (size_t)(ks * nk) * 64;
+    } else {
+        setup_run();
+    }
     if constexpr (NST == 2) {
         issue(0);
+#if MTTS_EPI_PRE == 2
+        if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+#endif
         ln_stats();
         gnr_prologue();
         __syncthreads();                       // (emits vmcnt(0): the first tile has landed)
@@ -342,13 +386,19 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nk) issue(buf ^ 1);   // the other buffer was last read before the barrier that ended step kt-1
-            compute(lds + buf * STAGE);
+            compute(lds_k + buf * STAGE);
             __syncthreads();                   // tile kt+1 landed (vmcnt(0)) and everyone is done reading tile kt
         }
     } else {
         constexpr int D = NST - 1;             // tiles in flight: the one about to be computed + D-1 behind it
         constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
         for (int t = 0; t < D && t < nk; ++t) issue(t);
+#if MTTS_EPI_PRE == 2
+        // the residual image tile of a 64-row tile: requested right behind the first D tiles; its R loads sit in the
+        // vector-memory counter between tile D-1 and tile D, so the first D counted waits allow R more (loads retire in order)
+        if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+#endif
+        const int pre_r = (BM == 64 && MTTS_EPI_PRE == 2 && pre.valid) ? (p.half16 ? 4 : 8) : 0;
         ln_stats();
         gnr_prologue();
         int st = 0;
@@ -356,19 +406,34 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
             // Tile kt has landed for this wave once at most the D-1 younger tiles are outstanding (the ring's tail just
             // drains); lgkmcnt(0): this wave's fragment reads of tile kt-1 are complete, so after the barrier that tile's
             // stage may be refilled.  Raw s_barrier: __syncthreads() would wait for every DMA in flight.
-            if (kt + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + D - 1 < nk) {
+                if (kt < D && pre_r == 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE + 8) : "memory");
+                else if (kt < D && pre_r == 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE + 4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt == 0) MTTS_STAMP(1);
-            if (kt + D < nk) issue(st + D >= NST ? st + D - NST : st + D);
-            compute(lds + st * STAGE);
+            // Split-K: the two wave sets share every barrier, so they would run in lockstep -- all eight waves issuing DMA pieces
+            // (~100 cycles each beside fragment reads), then all eight on the MFMA pipes.  The second set therefore computes
+            // first and requests afterwards: one set's MFMAs run under the other's DMA issue.  (Same hazards either way: the
+            // stage being refilled was last read in step kt-1, before the barrier above; the request still precedes the next
+            // counted wait, so the counts hold.)
+            const int nxt = st + D >= NST ? st + D - NST : st + D;
+            if (KS == 1 || ks == 0) {
+                if (kt + D < nk) issue(nxt);
+                compute(lds_k + st * STAGE);
+            } else {
+                compute(lds_k + st * STAGE);
+                if (kt + D < nk) issue(nxt);
+            }
             st = st + 1 == NST ? 0 : st + 1;
         }
         __syncthreads();                       // the epilogue tile overlays the stages: everyone is done reading
     }
 
     MTTS_STAMP(2);
-    // ---- epilogue: park the wave's tile in LDS, re-read it as rows of float4 (16 lanes per row)
-    float* Cw = reinterpret_cast<float*>(lds) + wave * ((BM / 2) * P16_CS);
+    if constexpr (BM != 64) cols = epi_load_cols<LN>(p, n0, wn, lane);      // (their flight overlaps the parking below)
+    // ---- epilogue: park the wave's tile in LDS, re-read it as rows of 2 x float4 (8 lanes per row)
+    float* Cw = reinterpret_cast<float*>(lds) + (ks * 4 + wave) * ((BM / 2) * P16_CS);
     if constexpr (M16) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -386,21 +451,30 @@ __global__ __launch_bounds__(256, 2) void gemm_p16_kernel(const GemmArgs p) {
                 for (int r = 0; r < 16; ++r)
                     Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh32) * P16_CS + j * 32 + fr32] = acc32[i][j][r] + accx32[i][j][r] * (1.0f / F16_RES_SCALE);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
-    __builtin_amdgcn_wave_barrier();
+    const float* Cw2 = nullptr;            // the second set's partial tile (KS = 2)
+    if constexpr (KS > 1) {
+        __syncthreads();                   // every set's partial tile is parked
+        if (ks != 0) return;               // (the first set finishes the tile; one wave per SIMD, as a one-per-CU grid had anyway)
+        Cw2 = Cw + 4 * ((BM / 2) * P16_CS);
+    } else {
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
+        __builtin_amdgcn_wave_barrier();
+    }
+    MTTS_STAMP(6);
 
-    gemm_epilogue_rows8<BM, LN, GN>(p, Cw, srow, M, m0, n0, wm, wn, lane, srow);    // (gstat shares srow's slot: never both)
+    gemm_epilogue_rows8<BM, LN, GN>(p, cols, pre, Cw, Cw2, srow, M, m0, n0, wm, wn, lane, srow);    // (gstat shares srow's slot: never both)
     MTTS_STAMP(3);
     MTTS_STAMP_RT(5);
 }
 
 // MFMA shape: 16x16x32 wherever a CU holds more than one workgroup (+10 % at B = 32), 32x32x16 on the 4-stage ring (grids of
 // at most one workgroup per CU are latency-bound and lose 4 % with the longer 16x16 issue sequence; B <= 8 serving shapes).
-template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false>
+template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false, int KS = 1>
 static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;   // per instantiation
-    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16, GN>;
-    constexpr int lds_bytes = p16_lds_bytes(BM, NST);
+    auto kern = gemm_p16_kernel<BM, LN, NST, MODE, M16, GN, KS>;
+    constexpr int lds_bytes = p16_lds_bytes(BM, NST, KS);
+    static_assert(lds_bytes <= 160 * 1024, "LDS per workgroup");
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -408,8 +482,18 @@ static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     }
     const int M = a.B * a.T_out;
     const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * KS), lds_bytes, s, a);
     return hipGetLastError();
+}
+
+// the split-K form of a one-workgroup-per-CU grid: 64-row tiles, two 4-wave sets on 3-stage rings, 16x16x32 MFMAs (two waves
+// per SIMD, as with two co-resident workgroups)
+template <bool LN, int MODE>
+static hipError_t launch_p16_splitk(const GemmArgs& a, hipStream_t s) {
+    if constexpr (!LN && MODE != 1) {
+        if (a.gn_stats) return launch_p16_shape<64, LN, 3, MODE, true, true, 2>(a, s);
+    }
+    return launch_p16_shape<64, LN, 3, MODE, true, false, 2>(a, s);
 }
 
 template <int BM, bool LN, int NST, int MODE>
@@ -498,6 +582,14 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
             return hipErrorInvalidValue;
     }
     if (bm == 64) {
+        // one workgroup per CU or fewer: split the K axis between two wave sets when it divides (MTTS_P16_SPLITK=0: the 4-stage ring)
+        static const int splitk = [] { const char* e = getenv("MTTS_P16_SPLITK"); return e ? atoi(e) : 1; }();
+        const int nk_all = a.ntaps * a.ktap / kq;
+        if (nst == 4 && splitk && nk_all >= 4 && (nk_all % 2) == 0) {
+            if (a.half16) return ln ? launch_p16_splitk<true, 2>(a, s) : launch_p16_splitk<false, 2>(a, s);
+            if (a.fast16) return ln ? launch_p16_splitk<true, 1>(a, s) : launch_p16_splitk<false, 1>(a, s);
+            return ln ? launch_p16_splitk<true, 0>(a, s) : launch_p16_splitk<false, 0>(a, s);
+        }
         if (nst == 4) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
         if (nst == 3) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
         return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);

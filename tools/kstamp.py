@@ -18,14 +18,16 @@ sys.path.insert(0, str(ROOT))
 PKG = "matcha-tts-24k_amd"
 
 
-def build():
+def build(extra=(), name="kstamp", nostamp=False):
     pk = ROOT / PKG
-    obj = "/tmp/gemm_p16_kstamp.o"
+    obj = f"/tmp/gemm_p16_{name}.o"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-           "-DMTTS_KSTAMP", "-c", str(pk / "csrc" / "gemm_p16.hip"), "-o", obj]
+           "-DMTTS_KSTAMP", *extra, "-c", str(pk / "csrc" / "gemm_p16.hip"), "-o", obj]
+    if nostamp:                                                # an A/B library without the stamps (bench.py under MTTS_HIP_LIB)
+        cmd.remove("-DMTTS_KSTAMP")
     subprocess.run(cmd, check=True)
     others = [str(pk / "build" / f"{n}.o") for n in ("gemm_f32", "attention_f32", "norm_glue", "vocos", "model")]
-    out = ROOT / "tools" / "ab" / "kstamp.so"
+    out = ROOT / "tools" / "ab" / f"{name}.so"
     out.parent.mkdir(exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", str(out)], check=True)
     print("built", out)
@@ -35,9 +37,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--flags", default="", help="extra compile flags for --build, e.g. -DMTTS_EPI_ROLL")
+    ap.add_argument("--name", default="kstamp", help="tools/ab/<name>.so")
+    ap.add_argument("--nostamp", action="store_true", help="--build without -DMTTS_KSTAMP")
+    ap.add_argument("--thrash", action="store_true", help="run the other shapes' kernels between the repeats (cold instruction cache)")
     args = ap.parse_args()
     if args.build:
-        return build()
+        return build(args.flags.split(), args.name, args.nostamp)
     import torch
     hip = importlib.import_module(PKG + "._hip")
     lib = hip.load()
@@ -58,6 +64,7 @@ def main():
         ("L1 ff2", 161, 1536, 1, 384, "res"),
     ]
     print(f"{'shape':38s} {'WGs':>5s} {'nk':>3s} | {'first tile':>10s} {'cyc/k-step':>10s} {'epilogue':>9s} | {'WG us':>6s} {'span us':>7s} {'GHz':>5s}")
+    calls = []
     for name, T, Cc, nt, N, kind in shapes:
         a = torch.randn(B * T, Cc, device=dev)
         w = torch.randn(N, Cc, nt, device=dev) * (Cc * nt) ** -0.5 if nt > 1 else torch.randn(N, Cc, device=dev) * Cc ** -0.5
@@ -69,8 +76,15 @@ def main():
             kw.update(act=3, p0=torch.ones(N, device=dev), p1=torch.ones(N, device=dev), want_f32=False, want_p16=True)
         if kind == "res":
             kw.update(res=torch.randn(B * T, N, device=dev), want_p16=True, stats_out=True)
+        calls.append((a, w, bias, kw))
+    for i, (name, T, Cc, nt, N, kind) in enumerate(shapes):
+        a, w, bias, kw = calls[i]
         stamps = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
         for rep in range(3):                                   # the last launch is the one read
+            if args.thrash:                                    # the other shapes' kernels in between, as inside a decoder block
+                for j, (a2, w2, b2, kw2) in enumerate(calls):
+                    if j != i:
+                        hip.gemm_p16(a2, w2, b2, **kw2)
             stamps.zero_()
             lib.mtts_debug_set_kstamp(stamps.data_ptr())
             hip.gemm_p16(a, w, bias, **kw)
@@ -88,7 +102,8 @@ def main():
         span_us = float(s[:, 5].max() - s[:, 4].min()) / 100.0
         med = statistics.median
         print(f"{name:38s} {len(s):5d} {nk:3d} | {med(first):10.0f} {med(loop):10.0f} {med(epi):9.0f} | "
-              f"{float(life.median()) / (ghz * 1e3):6.1f} {span_us:7.1f} {ghz:5.2f}", flush=True)
+              f"{float(life.median()) / (ghz * 1e3):6.1f} {span_us:7.1f} {ghz:5.2f} | park {med((s[:, 6] - s[:, 2]).tolist()):5.0f} "
+              f"chunk0 {med((s[:, 7] - s[:, 6]).tolist()):6.0f} rest {med((s[:, 3] - s[:, 7]).tolist()):6.0f}", flush=True)
 
 
 if __name__ == "__main__":
