@@ -301,7 +301,7 @@ struct EpiCols {                                             // a lane's 8 colum
     f32x4_e bias[2], s0[2], s1[2], ws[2];
 };
 template <int BM>
-struct EpiPre {                                              // residual image rows of a 64-row tile (4 passes), else unused
+struct EpiPre {                                              // residual image rows of a 64-row tile (<= 4 passes), else unused
     static constexpr int N = BM == 64 ? 4 : 1;
     f16x8_e h[N], l[N];
     bool valid;
@@ -332,8 +332,8 @@ __device__ __forceinline__ int epi_out_row(const GemmArgs& p, int m, int M, bool
     return b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
 }
 
-template <int BM>
-__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<BM>& pre, int M, int m0, int n0, int wm, int wn, int lane) {
+template <int BM, int NPASS = 4>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<BM>& pre, int M, int m0, int n0, int wm, int wn, int lane, int row0 = 0) {
     pre.valid = false;
     if constexpr (BM == 64) {
         if (p.res16 && !p.gnr_y) {                           // (an image implies N % 32 == 0: a lane's 8 columns are valid together)
@@ -342,8 +342,8 @@ __device__ __forceinline__ void epi_prefetch(const GemmArgs& p, EpiPre<BM>& pre,
             const int nc = n0 + wn * 64 + (lane & 7) * 8, rg = lane >> 3;
             const int ncl = nc < p.N ? nc : 0;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = epi_out_row(p, m0 + wm * 32 + it * 8 + rg, M, plain_rows);
+            for (int it = 0; it < NPASS; ++it) {
+                const int r = epi_out_row(p, m0 + wm * 32 + row0 + it * 8 + rg, M, plain_rows);
                 if (p.half16) {
                     pre.h[it] = *reinterpret_cast<const f16x8_e*>(p.res16 + (size_t)r * p.ldr16 + ncl);
                     pre.l[it] = f16x8_e{0, 0, 0, 0, 0, 0, 0, 0};
@@ -381,13 +381,34 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float lscale, uns
     }
 }
 
-template <int BM, bool LN, bool GN = false>
-__device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const EpiCols& cols, const EpiPre<BM>& pre, const float* __restrict__ Cw,
+// GroupNorm-statistics bookkeeping of a wave tile (wave-uniform; loaded before the k-loop so that the per-utterance row counts'
+// round trip is off the epilogue): part 0 = tile rows [0, cnt0), part 1 = rows [bnd, bnd + cnt1)
+struct EpiGnRows { int bnd, cnt0, cnt1; };
+template <int BM>
+__device__ __forceinline__ EpiGnRows epi_gn_rows(const GemmArgs& p, int M, int m0, int wm) {
+    EpiGnRows g = {BM, 0, 0};
+    constexpr int rows_w = BM / 2;
+    const int row_w0 = m0 + wm * rows_w;
+    if (p.gn_stats && row_w0 < M) {
+        const int b0 = row_w0 / p.T_out, t_w0 = row_w0 - b0 * p.T_out;
+        const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
+        const int nr1 = (b0 + 1 < p.B) ? (p.gn_nrows ? min(p.T_out, p.gn_nrows[b0 + 1]) : p.T_out) : 0;
+        g.bnd = min(rows_w, p.T_out - t_w0);
+        g.cnt0 = max(0, min(g.bnd, nr0 - t_w0));
+        g.cnt1 = max(0, min(rows_w - g.bnd, nr1));
+    }
+    return g;
+}
+
+// NPASS / row0: the passes this wave runs and the first wave-tile row they cover (split-K: the two wave sets share a tile's rows).
+template <int BM, bool LN, bool GN = false, int NPASS = BM / 16>
+__device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const EpiCols& cols, const EpiPre<BM>& pre, const EpiGnRows& gnr0, const float* __restrict__ Cw,
                                                     const float* __restrict__ Cw2, const float* __restrict__ srow, int M, int m0, int n0, int wm, int wn, int lane,
-                                                    const float* __restrict__ gstat = nullptr) {
+                                                    const float* __restrict__ gstat = nullptr, int row0 = 0) {
     using f32x4 = f32x4_e;
     using f16x8 = f16x8_e;
-    constexpr int NIT = BM / 16;                             // passes: 8 rows per pass
+    static_assert(!GN || NPASS == BM / 16, "GroupNorm statistics are per whole wave tile");
+    constexpr int NIT = NPASS;                               // passes: 8 rows per pass
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int co = lane & 7, rg = lane >> 3;
     const int nc = n0 + wn * 64 + co * 8;                   // first of this lane's 8 columns
@@ -417,7 +438,8 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     // ---- GroupNorm statistics (see gemm_epilogue_rows): per wave tile, utterance part and group slice; a lane's 8 columns lie in
     // one group (channels per group % 8 == 0)
     const bool gn = GN && p.gn_stats != nullptr;
-    int gn_gi = 0, gn_cols0 = 64, gn_bnd = BM, gn_cnt0 = 0, gn_cnt1 = 0;
+    int gn_gi = 0, gn_cols0 = 64;
+    const int gn_bnd = gnr0.bnd, gn_cnt0 = gnr0.cnt0, gn_cnt1 = gnr0.cnt1;
     float gn_mean[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gn_mu0 = 0.f, gn_mu1 = 0.f, gn_q0 = 0.f, gn_q1 = 0.f;
     if constexpr (GN) if (gn) {
         constexpr int rows_w = BM / 2;
@@ -425,14 +447,6 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
         const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
         gn_cols0 = min(64, (g0 + 1) * cpg - n0w);
         gn_gi = (nc / cpg) - g0;
-        if (row_w0 < M) {
-            const int b0 = row_w0 / p.T_out, t_w0 = row_w0 - b0 * p.T_out;
-            const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
-            const int nr1 = (b0 + 1 < p.B) ? (p.gn_nrows ? min(p.T_out, p.gn_nrows[b0 + 1]) : p.T_out) : 0;
-            gn_bnd = min(rows_w, p.T_out - t_w0);
-            gn_cnt0 = max(0, min(gn_bnd, nr0 - t_w0));
-            gn_cnt1 = max(0, min(rows_w - gn_bnd, nr1));
-        }
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -494,7 +508,7 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
             constexpr int c0 = decltype(c0_c)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int m = m0 + wm * (BM / 2) + (c0 + u) * 8 + rg;
+                const int m = m0 + wm * (BM / 2) + row0 + (c0 + u) * 8 + rg;
                 L.ok[u] = m < M;
                 const int r = epi_out_row(p, m, M, plain_rows);
                 L.orow[u] = r;
@@ -528,7 +542,7 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
         auto process_chunk = [&](int c0, const ChunkLoads& L) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int rl = (c0 + u) * 8 + rg;
+                const int rl = row0 + (c0 + u) * 8 + rg;
                 const float* q = Cw + rl * GEMM_CS + co * 8;
                 f32x4 o[2] = {*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4)};
                 if (Cw2) {                                   // split-K: the second wave set's partial sums

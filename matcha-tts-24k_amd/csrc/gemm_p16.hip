@@ -33,7 +33,11 @@ namespace mtts {
 
 #ifdef MTTS_KSTAMP
 static unsigned long long* g_kstamp = nullptr;            // diagnostic build: where the next launches put their stamps
-extern "C" void mtts_debug_set_kstamp(unsigned long long* p) { g_kstamp = p; }
+static int g_kstamp_skip = 0;                              // P16 GEMM launches to let pass first (in-situ: the n-th launch of a step)
+static int g_kstamp_info[8];                               // the stamped launch: M, N, K, tile rows, stages, wave sets, taps, flags
+extern "C" void mtts_debug_set_kstamp(unsigned long long* p) { g_kstamp = p; g_kstamp_skip = 0; }
+extern "C" void mtts_debug_set_kstamp_nth(unsigned long long* p, int n) { g_kstamp = p; g_kstamp_skip = n; }
+extern "C" void mtts_debug_kstamp_info(int* out) { for (int i = 0; i < 8; ++i) out[i] = g_kstamp_info[i]; }
 #endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -83,7 +87,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
 
     const int tid_all = threadIdx.x;
     const int ks = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid_all >> 8);      // which part of the K axis (wave-uniform)
-    const int tid = tid_all & 255, lane = tid & 63, wave = tid >> 6;                // position inside the 4-wave set
+    const int tid = tid_all & 255, lane = tid & 63;                                 // position inside the 4-wave set
+    // the wave index as a SCALAR: every LDS destination of a DMA piece is then an SGPR expression (s_add + s_mov m0) instead of
+    // a v_readfirstlane per piece, and the fragment / tile bases derived from it stay off the vector ALU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const lds_k = lds + ks * (NST * STAGE);                                   // this set's ring
     const int wm = wave >> 1, wn = wave & 1;
     const int M = p.B * p.T_out;
@@ -346,16 +353,24 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     // epilogue operands whose round trip should hide under the k-loop: the residual image tile (64-row tiles) and, where the
     // register budget allows (64-row tiles again), the column constants; requested BEFORE the first tiles so that they are the
     // oldest entries of the vector-memory counter and the ring's counted waits stay exact
+    // split-K epilogue: without GroupNorm statistics both wave sets finish the tile, half of every wave tile's rows each (two
+    // waves per SIMD keep the vector ALU issuing every cycle pair); with them (per whole wave tile) the first set does it alone
+    constexpr bool EPI_SPLIT = KS > 1 && !GN;
+    constexpr int EPI_PASS = EPI_SPLIT ? BM / 16 / KS : BM / 16;
+    const int epi_row0 = EPI_SPLIT ? ks * (BM / 2 / KS) : 0;
+    const bool epi_wave = EPI_SPLIT || ks == 0;               // does this wave run an epilogue
     EpiPre<BM> pre;
     pre.valid = false;
 #ifndef MTTS_EPI_PRE
 #define MTTS_EPI_PRE 2
 #endif
 #if MTTS_EPI_PRE == 1
-    if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+    if (epi_wave) epi_prefetch<BM, EPI_PASS>(p, pre, M, m0, n0, wm, wn, lane, epi_row0);
 #endif
     EpiCols cols;
-    if constexpr (BM == 64) { if (ks == 0) cols = epi_load_cols<LN>(p, n0, wn, lane); }
+    if constexpr (BM == 64) { if (epi_wave) cols = epi_load_cols<LN>(p, n0, wn, lane); }
+    EpiGnRows gn_rows = {BM, 0, 0};
+    if constexpr (GN) gn_rows = epi_gn_rows<BM>(p, M, m0, wm);
     if constexpr (KS > 1) {                     // this set's first k-step: walk the runs (tap, segment) up to step ks * nk
         int skip = ks * nk;
         for (;;) {
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     if constexpr (NST == 2) {
         issue(0);
 #if MTTS_EPI_PRE == 2
-        if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+        if (epi_wave) epi_prefetch<BM, EPI_PASS>(p, pre, M, m0, n0, wm, wn, lane, epi_row0);
 #endif
         ln_stats();
         gnr_prologue();
@@ -396,9 +411,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
 #if MTTS_EPI_PRE == 2
         // the residual image tile of a 64-row tile: requested right behind the first D tiles; its R loads sit in the
         // vector-memory counter between tile D-1 and tile D, so the first D counted waits allow R more (loads retire in order)
-        if (ks == 0) epi_prefetch<BM>(p, pre, M, m0, n0, wm, wn, lane);
+        if (epi_wave) epi_prefetch<BM, EPI_PASS>(p, pre, M, m0, n0, wm, wn, lane, epi_row0);
 #endif
-        const int pre_r = (BM == 64 && MTTS_EPI_PRE == 2 && pre.valid) ? (p.half16 ? 4 : 8) : 0;
+        const int pre_r = (BM == 64 && MTTS_EPI_PRE == 2 && pre.valid) ? (p.half16 ? EPI_PASS : 2 * EPI_PASS) : 0;
         ln_stats();
         gnr_prologue();
         int st = 0;
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
             if (kt + D - 1 < nk) {
                 if (kt < D && pre_r == 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE + 8) : "memory");
                 else if (kt < D && pre_r == 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE + 4) : "memory");
+                else if (kt < D && pre_r == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE + 2) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
             } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt == 0) MTTS_STAMP(1);
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     }
 
     MTTS_STAMP(2);
-    if constexpr (BM != 64) cols = epi_load_cols<LN>(p, n0, wn, lane);      // (their flight overlaps the parking below)
+    if constexpr (BM != 64) { if (epi_wave) cols = epi_load_cols<LN>(p, n0, wn, lane); }      // (their flight overlaps the parking below)
     // ---- epilogue: park the wave's tile in LDS, re-read it as rows of 2 x float4 (8 lanes per row)
     float* Cw = reinterpret_cast<float*>(lds) + (ks * 4 + wave) * ((BM / 2) * P16_CS);
     if constexpr (M16) {
@@ -451,10 +467,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
                 for (int r = 0; r < 16; ++r)
                     Cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh32) * P16_CS + j * 32 + fr32] = acc32[i][j][r] + accx32[i][j][r] * (1.0f / F16_RES_SCALE);
     }
-    const float* Cw2 = nullptr;            // the second set's partial tile (KS = 2)
+    const float* Cw2 = nullptr;            // the other set's partial tile (KS = 2)
     if constexpr (KS > 1) {
         __syncthreads();                   // every set's partial tile is parked
-        if (ks != 0) return;               // (the first set finishes the tile; one wave per SIMD, as a one-per-CU grid had anyway)
+        if (!epi_wave) return;
+        Cw = reinterpret_cast<float*>(lds) + wave * ((BM / 2) * P16_CS);            // partial sums in set order: run-to-run identical
         Cw2 = Cw + 4 * ((BM / 2) * P16_CS);
     } else {
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is private to this wave
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     }
     MTTS_STAMP(6);
 
-    gemm_epilogue_rows8<BM, LN, GN>(p, cols, pre, Cw, Cw2, srow, M, m0, n0, wm, wn, lane, srow);    // (gstat shares srow's slot: never both)
+    gemm_epilogue_rows8<BM, LN, GN, EPI_PASS>(p, cols, pre, gn_rows, Cw, Cw2, srow, M, m0, n0, wm, wn, lane, srow, epi_row0);    // (gstat shares srow's slot: never both)
     MTTS_STAMP(3);
     MTTS_STAMP_RT(5);
 }
@@ -571,7 +588,20 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
     int nst = 2;
     const int bm = p16_choose(a, nst);
 #ifdef MTTS_KSTAMP
-    if (g_kstamp) { GemmArgs b = a; b.kstamp = g_kstamp; g_kstamp = nullptr; return launch_gemm_p16(b, s); }     // one launch per set call
+    if (g_kstamp && g_kstamp_skip > 0) {
+        --g_kstamp_skip;
+    } else if (g_kstamp) {                                   // one launch per set call
+        GemmArgs b = a;
+        b.kstamp = g_kstamp;
+        g_kstamp = nullptr;
+        const int nk_all = a.ntaps * a.ktap / kq;
+        const bool sk = bm == 64 && nst == 4 && nk_all >= 4 && (nk_all % 2) == 0 && !(getenv("MTTS_P16_SPLITK") && atoi(getenv("MTTS_P16_SPLITK")) == 0);
+        const int info[8] = {a.B * a.T_out, a.N, a.ntaps * a.ktap, bm, sk ? 3 : nst, sk ? 2 : 1, a.ntaps,
+                             (ln ? 1 : 0) | (a.res16 ? 2 : 0) | (a.out16 ? 4 : 0) | (a.out ? 8 : 0) | (a.gn_stats ? 16 : 0) | (a.gnr_y ? 32 : 0) |
+                                 (a.act == ACT_SNAKE ? 64 : 0) | (a.stats_out ? 128 : 0)};
+        for (int i = 0; i < 8; ++i) g_kstamp_info[i] = info[i];
+        return launch_gemm_p16(b, s);
+    }
 #endif
     if (a.gnr_y) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
