@@ -21,6 +21,9 @@ __device__ __forceinline__ void split_f16(float x, float lscale, _Float16& h, _F
     l = (_Float16)((xc - (float)h) * lscale);
 }
 
+// n / d by a host-made reciprocal (rcp = floor(2^32 / d) + 1; exact while n * d < 2^32; d <= 1 passes n through)
+__device__ __forceinline__ int fdiv(int n, int d, unsigned int rcp) { return d <= 1 ? n : (int)__umulhi((unsigned int)n, rcp); }
+
 // Range guard of the fp16 split: an operand beyond +-65504 saturates (h clamps), which the caller must learn about.  Producers
 // OR their lanes' findings into a register and raise the sticky flag once per thread (atomics only on the rare bad path).
 __device__ __forceinline__ bool out_of_f16_range(float a, float b, float c, float d) {

@@ -304,7 +304,8 @@ template <int BM>
 struct EpiPre {                                              // residual image rows of a 64-row tile (<= 4 passes), else unused
     static constexpr int N = BM == 64 ? 4 : 1;
     f16x8_e h[N], l[N];
-    bool valid;
+    float om[N], om16[N];                                    // out_mask / out16_mask of the pass's row (1 where there is no mask)
+    bool valid;                                              // h / l hold the residual image
 };
 
 template <bool LN>
@@ -328,8 +329,22 @@ __device__ __forceinline__ EpiCols epi_load_cols(const GemmArgs& p, int n0, int 
 __device__ __forceinline__ int epi_out_row(const GemmArgs& p, int m, int M, bool plain_rows) {
     const int mc = m < M ? m : M - 1;
     if (plain_rows) return mc;
-    const int b = mc / p.T_out;
+    const int b = fdiv(mc, p.T_out, p.rcp_T_out);
     return b * p.out_T + (mc - b * p.T_out) * p.out_stride + p.out_off;
+}
+
+// the row masks of a 64-row tile's passes: small L2-resident loads, requested BEFORE the first tiles (oldest in the counter)
+template <int BM, int NPASS = 4>
+__device__ __forceinline__ void epi_prefetch_masks(const GemmArgs& p, EpiPre<BM>& pre, int M, int m0, int wm, int lane, int row0 = 0) {
+    if constexpr (BM == 64) {
+        const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
+#pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+            const int r = epi_out_row(p, m0 + wm * 32 + row0 + it * 8 + (lane >> 3), M, plain_rows);
+            pre.om[it] = p.out_mask ? p.out_mask[r] : 1.0f;
+            pre.om16[it] = p.out16_mask ? p.out16_mask[r] : 1.0f;
+        }
+    }
 }
 
 template <int BM, int NPASS = 4>
@@ -390,7 +405,7 @@ __device__ __forceinline__ EpiGnRows epi_gn_rows(const GemmArgs& p, int M, int m
     constexpr int rows_w = BM / 2;
     const int row_w0 = m0 + wm * rows_w;
     if (p.gn_stats && row_w0 < M) {
-        const int b0 = row_w0 / p.T_out, t_w0 = row_w0 - b0 * p.T_out;
+        const int b0 = fdiv(row_w0, p.T_out, p.rcp_T_out), t_w0 = row_w0 - b0 * p.T_out;
         const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
         const int nr1 = (b0 + 1 < p.B) ? (p.gn_nrows ? min(p.T_out, p.gn_nrows[b0 + 1]) : p.T_out) : 0;
         g.bnd = min(rows_w, p.T_out - t_w0);
@@ -444,9 +459,9 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     if constexpr (GN) if (gn) {
         constexpr int rows_w = BM / 2;
         const int row_w0 = m0 + wm * rows_w;
-        const int cpg = p.N / p.gn_groups, n0w = n0 + wn * 64, g0 = n0w / cpg;
+        const int cpg = p.gn_cpg, n0w = n0 + wn * 64, g0 = fdiv(n0w, cpg, p.rcp_gn_cpg);
         gn_cols0 = min(64, (g0 + 1) * cpg - n0w);
-        gn_gi = (nc / cpg) - g0;
+        gn_gi = nc - n0w >= gn_cols0 ? 1 : 0;                // (channels per group >= 32: a wave's 64 columns lie in at most two groups)
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -481,12 +496,12 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     int gnr_bnd = 0x7fffffff;
     f32x4 gnr_gm[2] = {zero4, zero4}, gnr_bt[2] = {zero4, zero4};
     if (p.gnr_y && ok_a) {
-        const int cpg = p.N / p.gnr_groups, gl = nc / cpg - n0 / cpg;
+        const int cpg = p.gnr_cpg, gl = fdiv(nc, cpg, p.rcp_gnr_cpg) - fdiv(n0, cpg, p.rcp_gnr_cpg);
         gnr_mu = gstat[gl];
         gnr_rs = gstat[4 + gl];
         gnr_mu1 = gstat[8 + gl];
         gnr_rs1 = gstat[12 + gl];
-        gnr_bnd = (m0 / p.T_out + 1) * p.T_out;
+        gnr_bnd = (fdiv(m0, p.T_out, p.rcp_T_out) + 1) * p.T_out;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             gnr_gm[h] = *reinterpret_cast<const f32x4*>(p.gnr_gamma + nc + 4 * h);
@@ -512,8 +527,13 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
                 L.ok[u] = m < M;
                 const int r = epi_out_row(p, m, M, plain_rows);
                 L.orow[u] = r;
-                L.om[u] = (a_om ? a_om[r] : 1.0f) * a_scale;    // the mask is 0 or 1: one factor serves both
-                L.om16[u] = a_om16 ? a_om16[r] : 1.0f;
+                if constexpr (BM == 64) {                    // requested before the k-loop (epi_prefetch_masks)
+                    L.om[u] = pre.om[c0 + u] * a_scale;
+                    L.om16[u] = pre.om16[c0 + u];
+                } else {
+                    L.om[u] = (a_om ? a_om[r] : 1.0f) * a_scale;    // the mask is 0 or 1: one factor serves both
+                    L.om16[u] = a_om16 ? a_om16[r] : 1.0f;
+                }
                 const int ncl = ok_a ? nc : 0, ncb = ok_b ? nc + 4 : 0;
                 if constexpr (RESK == 1) {
                     L.rres[u][0] = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + ncl);

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
         const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int m0 = (swz / n_tiles) * BM;
-    const int n0 = (swz % n_tiles) * GEMM_BN;
+    const int mt = fdiv(swz, n_tiles, p.rcp_ntiles);
+    const int m0 = mt * BM;
+    const int n0 = (swz - mt * n_tiles) * GEMM_BN;
 
     // ---- DMA coordinates.  Piece pa of the A tile = rows 8 pa .. 8 pa + 7; lane i fills LDS bytes [16 i, 16 i + 16) of the
     // piece = row i>>3, slot i&7, which must hold chunk (i&7) ^ ((row>>1)&7), row>>1 = 4 pa + (i>>4).
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
         const int m = m0 + pa * 8 + (lane >> 3);
         a_chunk[j] = ((lane & 7) ^ (((pa & 1) * 4 + (lane >> 4)) & 7)) * 8;
         if (m < M) {
-            const int b = m / p.T_out;
+            const int b = fdiv(m, p.T_out, p.rcp_T_out);
             a_base[j] = b * p.T_in;
             a_t[j] = (m - b * p.T_out) * p.in_stride;
         } else {
@@ -289,12 +290,19 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     // A workgroup's rows lie in at most two utterances (T_out >= BM): wave 0 merges for the first, wave 1 for the second.
     auto gnr_prologue = [&]() {
         if (p.gnr_y && tid_all < 128) {
-            const int cpg = p.N / p.gnr_groups, gl = (tid & 63) >> 4, j = tid & 15, g = n0 / cpg + gl;
-            const int b = m0 / p.T_out + (tid >> 6);
+            const int cpg = p.gnr_cpg, gl = (tid & 63) >> 4, j = tid & 15, g = fdiv(n0, cpg, p.rcp_gnr_cpg) + gl;
+            const int b = fdiv(m0, p.T_out, p.rcp_T_out) + (tid >> 6);
             const bool live = g < p.gnr_groups && g * cpg < min(p.N, n0 + GEMM_BN) && b < p.B;
             const int ncw = p.N >> 6, R = p.gnr_tile_rows;
-            const int t_first = (b * p.T_out) / R, nrw = ((b + 1) * p.T_out - 1) / R - t_first + 1;     // wave tiles touching utterance b
+            const int t_first = fdiv(b * p.T_out, R, p.rcp_gnr_R), nrw = fdiv((b + 1) * p.T_out - 1, R, p.rcp_gnr_R) - t_first + 1;     // wave tiles touching utterance b
             float n = 0.f, mean = 0.f, m2 = 0.f;
+            // (the closed-form bias rows' operands are requested with the entries: one round trip, not two)
+            float x_ne = 0.f, x_bm = 0.f, x_bq = 0.f;
+            if (live && p.gnr_nextra && j == 0) {
+                x_ne = (float)p.gnr_nextra[b];
+                x_bm = p.gnr_bias_stats[2 * g];
+                x_bq = p.gnr_bias_stats[2 * g + 1];
+            }
             if (live) {
                 const int w_lo = (g * cpg) >> 6, w_hi = ((g + 1) * cpg - 1) >> 6, nw = w_hi - w_lo + 1;
                 // entries in batches of 8 per lane: the loads of a batch are independent (one round trip), the merge order is fixed
@@ -305,18 +313,18 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
                     for (int e = 0; e < 8; ++e) {
                         const int k = k0 + 16 * e;
                         const int kc = k < total ? k : j;
-                        const int rw = kc / nw, w = w_lo + (kc - rw * nw), tile = t_first + rw;
-                        const int part = (tile * R) / p.T_out == b ? 0 : 1;
-                        q[e] = *reinterpret_cast<const f32x4*>(p.gnr_stats + ((size_t)(((size_t)tile * 2 + part) * ncw + w) * 2 + (g - (w * 64) / cpg)) * 4);
+                        const int rw = nw == 1 ? kc : (nw == 2 ? kc >> 1 : kc / nw), w = w_lo + (kc - rw * nw), tile = t_first + rw;
+                        const int part = tile * R >= b * p.T_out ? 0 : 1;       // (a tile that starts in the previous utterance holds b's rows as its part 1)
+                        q[e] = *reinterpret_cast<const f32x4*>(p.gnr_stats + ((size_t)(((size_t)tile * 2 + part) * ncw + w) * 2 + (g - fdiv(w * 64, cpg, p.rcp_gnr_cpg))) * 4);
                         if (k >= total) q[e][0] = 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float nb = q[e][0];
                         if (nb <= 0.f) continue;
-                        const float delta = q[e][1] - mean, nt = n + nb;
-                        mean += delta * (nb / nt);
-                        m2 += q[e][2] + delta * delta * (n * nb / nt);
+                        const float delta = q[e][1] - mean, nt = n + nb, r = nb / nt;      // one division per entry
+                        mean += delta * r;
+                        m2 += q[e][2] + delta * delta * (n * r);
                         n = nt;
                     }
                 }
@@ -324,10 +332,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
             for (int off = 1; off < 16; off <<= 1) {
                 const float n2 = __shfl_xor(n, off), mean2 = __shfl_xor(mean, off), m22 = __shfl_xor(m2, off);
                 const float nt = n + n2;
-                if (nt > 0.f) {
-                    const float delta = mean2 - mean, w2 = n2 / nt;
-                    const float merged = (j & off) ? mean2 + (mean - mean2) * (n / nt) : mean + delta * w2;
-                    m2 = m2 + m22 + delta * delta * (n * w2);
+                if (nt > 0.f) {       // both lanes of a pair form the same mean (the lower lane's expression); one division each
+                    const bool up = (j & off) != 0;
+                    const float delta = mean2 - mean, wsel = (up ? n : n2) / nt;
+                    const float merged = up ? mean2 + (mean - mean2) * wsel : mean + delta * wsel;
+                    m2 = m2 + m22 + delta * delta * ((up ? n2 : n) * wsel);
                     mean = merged;
                     n = nt;
                 }
@@ -335,11 +344,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
             float* gs = srow + (tid >> 6) * 8;
             if (j == 0) {
                 if (live && p.gnr_nextra) {            // folded padding: nextra copies of the conv's bias row (closed form)
-                    const float ne = (float)p.gnr_nextra[b];
+                    const float ne = x_ne;
                     if (ne > 0.f) {
-                        const float nb = ne * (float)cpg, delta = p.gnr_bias_stats[2 * g] - mean, nt = n + nb;
-                        mean += delta * (nb / nt);
-                        m2 += ne * p.gnr_bias_stats[2 * g + 1] + delta * delta * (n * nb / nt);
+                        const float nb = ne * (float)cpg, delta = x_bm - mean, nt = n + nb, r = nb / nt;
+                        mean += delta * r;
+                        m2 += ne * x_bq + delta * delta * (n * r);
                         n = nt;
                     }
                 }
@@ -368,7 +377,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     if (epi_wave) epi_prefetch<BM, EPI_PASS>(p, pre, M, m0, n0, wm, wn, lane, epi_row0);
 #endif
     EpiCols cols;
-    if constexpr (BM == 64) { if (epi_wave) cols = epi_load_cols<LN>(p, n0, wn, lane); }
+    if constexpr (BM == 64) {
+        if (epi_wave) {
+            cols = epi_load_cols<LN>(p, n0, wn, lane);
+            epi_prefetch_masks<BM, EPI_PASS>(p, pre, M, m0, wm, lane, epi_row0);
+        }
+    }
     EpiGnRows gn_rows = {BM, 0, 0};
     if constexpr (GN) gn_rows = epi_gn_rows<BM>(p, M, m0, wm);
     if constexpr (KS > 1) {                     // this set's first k-step: walk the runs (tap, segment) up to step ks * nk
@@ -558,7 +572,21 @@ int gemm_p16_wave_rows(const GemmArgs& a) {
     return p16_choose(a, nst) / 2;
 }
 
-hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s) {
+static unsigned int rcp32(int d) { return d <= 1 ? 0u : (unsigned int)((1ull << 32) / (unsigned long long)d + 1ull); }
+
+hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    {   // reciprocals for the kernel's index arithmetic (kernels.h); exactness needs n * d < 2^32 for every quotient taken
+        const long long Mp = (long long)a.B * a.T_out + 256;
+        if (a.B <= 0 || a.T_out <= 0 || a.N <= 0 || Mp * a.T_out >= (1ll << 32) || Mp * 64 >= (1ll << 32)) return hipErrorInvalidValue;
+        a.rcp_T_out = rcp32(a.T_out);
+        a.rcp_ntiles = rcp32((a.N + GEMM_BN - 1) / GEMM_BN);
+        a.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;
+        a.gnr_cpg = a.gnr_groups > 0 ? a.N / a.gnr_groups : 0;
+        a.rcp_gn_cpg = rcp32(a.gn_cpg);
+        a.rcp_gnr_cpg = rcp32(a.gnr_cpg);
+        a.rcp_gnr_R = rcp32(a.gnr_tile_rows);
+    }
     // shape contract (the kernel indexes without further checks)
     const int kq = a.half16 ? 64 : GEMM_BK, ew = a.half16 ? 1 : 2;      // k elements per 128-byte line; halves per element
     if (!a.a16_0 || (a.half16 ? !a.w16h : !a.w16) || a.terms != 2 || (!a.out && !a.out16) || a.N <= 0 || (a.N & 3) || a.B <= 0 || a.T_out <= 0 || a.T_in <= 0)

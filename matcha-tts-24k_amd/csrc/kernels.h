@@ -83,6 +83,11 @@ struct GemmArgs {
     const float* gnr_y = nullptr;     // [M][N] fp32 rows (ld = N)
     const float* gnr_stats = nullptr; // entries as GemmArgs::gn_stats of the producing conv
     int gnr_tile_rows = 0, gnr_groups = 0;
+    // filled by launch_gemm_p16 (host), not by callers: reciprocals for the P16 kernel's index arithmetic -- q = umulhi(n, rcp) is
+    // n / d exactly while n * d < 2^32 (device_utils.h fdiv; an integer division costs ~25 vector instructions, and a
+    // workgroup's prologue had ~20 of them in front of its first tile request)
+    unsigned int rcp_T_out = 0, rcp_ntiles = 0, rcp_gn_cpg = 0, rcp_gnr_cpg = 0, rcp_gnr_R = 0;
+    int gn_cpg = 0, gnr_cpg = 0;
     const float* gnr_gamma = nullptr; const float* gnr_beta = nullptr; const float* gnr_mask = nullptr;
     float gnr_eps = 1e-5f;
     const int* gnr_nextra = nullptr;      // folded padding (GnApplyArgs::nextra / bias_stats): copies of the producing conv's bias
