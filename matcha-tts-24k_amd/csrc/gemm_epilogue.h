@@ -399,11 +399,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float lscale, uns
 // GroupNorm-statistics bookkeeping of a wave tile (wave-uniform; loaded before the k-loop so that the per-utterance row counts'
 // round trip is off the epilogue): part 0 = tile rows [0, cnt0), part 1 = rows [bnd, bnd + cnt1)
 struct EpiGnRows { int bnd, cnt0, cnt1; };
-template <int BM>
-__device__ __forceinline__ EpiGnRows epi_gn_rows(const GemmArgs& p, int M, int m0, int wm) {
-    EpiGnRows g = {BM, 0, 0};
-    constexpr int rows_w = BM / 2;
-    const int row_w0 = m0 + wm * rows_w;
+// row_w0: first row of the wave's (sub-)tile, rows_w: its height (= the statistics' tile height the consumers are told)
+__device__ __forceinline__ EpiGnRows epi_gn_rows(const GemmArgs& p, int M, int row_w0, int rows_w) {
+    EpiGnRows g = {rows_w, 0, 0};
     if (p.gn_stats && row_w0 < M) {
         const int b0 = fdiv(row_w0, p.T_out, p.rcp_T_out), t_w0 = row_w0 - b0 * p.T_out;
         const int nr0 = p.gn_nrows ? min(p.T_out, p.gn_nrows[b0]) : p.T_out;
@@ -422,7 +420,8 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
                                                     const float* __restrict__ gstat = nullptr, int row0 = 0) {
     using f32x4 = f32x4_e;
     using f16x8 = f16x8_e;
-    static_assert(!GN || NPASS == BM / 16, "GroupNorm statistics are per whole wave tile");
+    // (GroupNorm statistics are per NPASS * 8 rows: the whole wave tile, or the 32-row half of a 128-row kernel's wave tile that a
+    // split-K wave set finishes -- the height gemm_p16_wave_rows() reports either way)
     constexpr int NIT = NPASS;                               // passes: 8 rows per pass
     const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.out_T == p.T_out);
     const int co = lane & 7, rg = lane >> 3;
@@ -457,21 +456,19 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     const int gn_bnd = gnr0.bnd, gn_cnt0 = gnr0.cnt0, gn_cnt1 = gnr0.cnt1;
     float gn_mean[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gn_mu0 = 0.f, gn_mu1 = 0.f, gn_q0 = 0.f, gn_q1 = 0.f;
     if constexpr (GN) if (gn) {
-        constexpr int rows_w = BM / 2;
-        const int row_w0 = m0 + wm * rows_w;
         const int cpg = p.gn_cpg, n0w = n0 + wn * 64, g0 = fdiv(n0w, cpg, p.rcp_gn_cpg);
         gn_cols0 = min(64, (g0 + 1) * cpg - n0w);
         gn_gi = nc - n0w >= gn_cols0 ? 1 : 0;                // (channels per group >= 32: a wave's 64 columns lie in at most two groups)
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int rl = it * 8 + rg;
+            const int rl = it * 8 + rg;                      // row inside this wave's (sub-)tile
             const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
             if (in0 || in1) {
-                const float* q = Cw + rl * GEMM_CS + co * 8;
+                const float* q = Cw + (row0 + rl) * GEMM_CS + co * 8;
                 f32x4 qa = *reinterpret_cast<const f32x4*>(q), qb = *reinterpret_cast<const f32x4*>(q + 4);
                 if (Cw2) {
-                    const float* q2 = Cw2 + rl * GEMM_CS + co * 8;
+                    const float* q2 = Cw2 + (row0 + rl) * GEMM_CS + co * 8;
                     qa += *reinterpret_cast<const f32x4*>(q2);
                     qb += *reinterpret_cast<const f32x4*>(q2 + 4);
                 }
@@ -579,7 +576,8 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
                     o[1] += bias[1];
                 }
                 if (GN && gn) {
-                    const bool in0 = rl < gn_cnt0, in1 = rl >= gn_bnd && rl < gn_bnd + gn_cnt1;
+                    const int rs = rl - row0;
+                    const bool in0 = rs < gn_cnt0, in1 = rs >= gn_bnd && rs < gn_bnd + gn_cnt1;
                     if (in0 || in1) {
                         const float mu = in0 ? gn_mu0 : gn_mu1;
                         const float t = sq4(o[0] - mu) + sq4(o[1] - mu);
@@ -694,12 +692,12 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     }
     raise_range_flag(p.range_flag, rmax > 65504.f);
     if constexpr (GN) if (gn) {
-        const int row_w0 = m0 + wm * (BM / 2), col_wave = (n0 + wn * 64) >> 6;
+        const int row_w0 = m0 + wm * (BM / 2) + row0, col_wave = (n0 + wn * 64) >> 6;
         const float q00 = allreduce64(gn_gi == 0 ? gn_q0 : 0.f), q01 = allreduce64(gn_gi == 1 ? gn_q0 : 0.f);
         float q10 = 0.f, q11 = 0.f;
         if (gn_cnt1 > 0) { q10 = allreduce64(gn_gi == 0 ? gn_q1 : 0.f); q11 = allreduce64(gn_gi == 1 ? gn_q1 : 0.f); }
         if (lane == 0 && row_w0 < M) {
-            const int tile = row_w0 / (BM / 2);
+            const int tile = row_w0 / (NPASS * 8);
             float* e = p.gn_stats + ((size_t)((tile * 2) * (p.N >> 6) + col_wave) * 2) * 4;
             *reinterpret_cast<f32x4*>(e) = f32x4{(float)(gn_cnt0 * gn_cols0), gn_mean[0][0], q00, 0.f};
             *reinterpret_cast<f32x4*>(e + 4) = f32x4{(float)(gn_cnt0 * (64 - gn_cols0)), gn_mean[0][1], q01, 0.f};

@@ -197,29 +197,35 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
         const char* sa = stage + (wm * (BM / 2) + fr) * 128;
         const char* sw = stage + BM * 128 + (wn * 64 + fr) * 128;
         const int sh = (fq ^ f8) * 16, sl = ((4 + fq) ^ f8) * 16;      // (row >> 1) & 7 == (fr >> 1) & 7: tile bases are multiples of 16
-        f16x8 ah[MT], al[MT], bh[4], bl[4];
+        constexpr int JB = (BM == 128 && KS > 1) ? 2 : 4;       // weight fragments held at a time (the 8-wave 128-row kernel has 256 registers per wave)
+        f16x8 ah[MT], al[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             ah[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sh);
             if constexpr (!ONE) al[i] = *reinterpret_cast<const f16x8*>(sa + i * 16 * 128 + sl);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bh[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sh);
-            if constexpr (!ONE) bl[j] = *reinterpret_cast<const f16x8*>(sw + j * 16 * 128 + sl);
-        }
+        for (int j0 = 0; j0 < 4; j0 += JB) {
+            if constexpr (JB < 4) __builtin_amdgcn_sched_barrier(0);      // (keep the next pair's fragment reads behind this pair's MFMAs: registers)
+            f16x8 bh[JB], bl[JB];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (HALF) {          // second 32-k half of the line
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bl[j], acc[i][j], 0, 0, 0);
-                } else if constexpr (!ONE) {
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
-                }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < JB; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(sw + (j0 + j) * 16 * 128 + sh);
+                if constexpr (!ONE) bl[j] = *reinterpret_cast<const f16x8*>(sw + (j0 + j) * 16 * 128 + sl);
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    if constexpr (HALF) {          // second 32-k half of the line
+                        acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bl[j], acc[i][j0 + j], 0, 0, 0);
+                    } else if constexpr (!ONE) {
+                        accx[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j0 + j], 0, 0, 0);
+                        accx[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j0 + j], 0, 0, 0);
+                    }
+                    acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j0 + j], 0, 0, 0);
+                }
+        }
     };
     auto compute32 = [&](const char* stage) {
         const char* sa = stage + (wm * (BM / 2) + fr32) * 128;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     // oldest entries of the vector-memory counter and the ring's counted waits stay exact
     // split-K epilogue: without GroupNorm statistics both wave sets finish the tile, half of every wave tile's rows each (two
     // waves per SIMD keep the vector ALU issuing every cycle pair); with them (per whole wave tile) the first set does it alone
-    constexpr bool EPI_SPLIT = KS > 1 && !GN;
+    constexpr bool EPI_SPLIT = KS > 1 && (!GN || BM == 128);     // (128-row kernels: a half wave tile is the 32 rows the statistics' consumers expect)
     constexpr int EPI_PASS = EPI_SPLIT ? BM / 16 / KS : BM / 16;
     const int epi_row0 = EPI_SPLIT ? ks * (BM / 2 / KS) : 0;
     const bool epi_wave = EPI_SPLIT || ks == 0;               // does this wave run an epilogue
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
         }
     }
     EpiGnRows gn_rows = {BM, 0, 0};
-    if constexpr (GN) gn_rows = epi_gn_rows<BM>(p, M, m0, wm);
+    if constexpr (GN) { if (epi_wave) gn_rows = epi_gn_rows(p, M, m0 + wm * (BM / 2) + epi_row0, EPI_PASS * 8); }
     if constexpr (KS > 1) {                     // this set's first k-step: walk the runs (tap, segment) up to step ks * nk
         int skip = ks * nk;
         for (;;) {
@@ -442,19 +448,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
                 else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((D - 1) * PER_TILE) : "memory");
             } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt == 0) MTTS_STAMP(1);
-            // Split-K: the two wave sets share every barrier, so they would run in lockstep -- all eight waves issuing DMA pieces
-            // (~100 cycles each beside fragment reads), then all eight on the MFMA pipes.  The second set therefore computes
-            // first and requests afterwards: one set's MFMAs run under the other's DMA issue.  (Same hazards either way: the
-            // stage being refilled was last read in step kt-1, before the barrier above; the request still precedes the next
-            // counted wait, so the counts hold.)
-            const int nxt = st + D >= NST ? st + D - NST : st + D;
-            if (KS == 1 || ks == 0) {
-                if (kt + D < nk) issue(nxt);
-                compute(lds_k + st * STAGE);
-            } else {
-                compute(lds_k + st * STAGE);
-                if (kt + D < nk) issue(nxt);
-            }
+            // (split-K: letting the second wave set compute first and request afterwards, so that one set's MFMAs run under the
+            // other's DMA issue, measured SLOWER than the two sets in lockstep: 26.58 vs 26.16 ms per step, r02)
+            if (kt + D < nk) issue(st + D >= NST ? st + D - NST : st + D);
+            compute(lds_k + st * STAGE);
             st = st + 1 == NST ? 0 : st + 1;
         }
         __syncthreads();                       // the epilogue tile overlays the stages: everyone is done reading
@@ -648,6 +645,8 @@ hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
             if (a.fast16) return ln ? launch_p16_splitk<true, 1>(a, s) : launch_p16_splitk<false, 1>(a, s);
             return ln ? launch_p16_splitk<true, 0>(a, s) : launch_p16_splitk<false, 0>(a, s);
         }
+        // (the same split on 128 x 128 tiles -- 64 x 64 per wave, one 8-wave workgroup per CU -- for the 257..512-tile grids measured
+        // slower than two co-resident 64-row workgroups: 27.26 vs 26.55 ms per step, r02)
         if (nst == 4) return ln ? launch_p16_variant<64, true, 4>(a, s) : launch_p16_variant<64, false, 4>(a, s);
         if (nst == 3) return ln ? launch_p16_variant<64, true, 3>(a, s) : launch_p16_variant<64, false, 3>(a, s);
         return ln ? launch_p16_variant<64, true>(a, s) : launch_p16_variant<64, false>(a, s);
