@@ -665,7 +665,9 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
         load_chunk(IntC<0>{}, LA);
         if constexpr (NIT > U) load_chunk(IntC<U>{}, LB);
         process_chunk(0, LA);
+#ifndef MTTS_KSTAMP_SETUP
         MTTS_STAMP(7);
+#endif
         if constexpr (NIT > 2 * U) load_chunk(IntC<2 * U>{}, LA);
         if constexpr (NIT > U) process_chunk(U, LB);
         if constexpr (NIT > 2 * U) {

@@ -427,6 +427,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     } else {
         constexpr int D = NST - 1;             // tiles in flight: the one about to be computed + D-1 behind it
         constexpr int PER_TILE = APW + 4;      // DMA instructions per tile and wave (the only VMEM ops in the loop)
+#ifdef MTTS_KSTAMP_SETUP
+        MTTS_STAMP(7);                         // (diagnostic: setup done, first tile about to be requested)
+#endif
         for (int t = 0; t < D && t < nk; ++t) issue(t);
 #if MTTS_EPI_PRE == 2
         // the residual image tile of a 64-row tile: requested right behind the first D tiles; its R loads sit in the

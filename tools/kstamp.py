@@ -45,7 +45,8 @@ def fmt_stamps(s, nk):
     span_us = float(s[:, 5].max() - s[:, 4].min()) / 100.0
     return (f"{len(s):5d} {nk:3d} | {med(first):10.0f} {med(loop):10.0f} {med(epi):9.0f} | "
             f"{float(life.median()) / (ghz * 1e3):6.1f} {span_us:7.1f} {ghz:5.2f} | park {med((s[:, 6] - s[:, 2]).tolist()):5.0f} "
-            f"chunk0 {med((s[:, 7] - s[:, 6]).tolist()):6.0f} rest {med((s[:, 3] - s[:, 7]).tolist()):6.0f}")
+            f"chunk0 {med((s[:, 7] - s[:, 6]).tolist()):6.0f} rest {med((s[:, 3] - s[:, 7]).tolist()):6.0f}"
+            f" | s7-s0 {med((s[:, 7] - s[:, 0]).tolist()):6.0f} (setup, -DMTTS_KSTAMP_SETUP builds only)")
 
 
 def insitu(args, lib, torch, dev):
