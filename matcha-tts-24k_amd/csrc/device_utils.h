@@ -21,8 +21,9 @@ __device__ __forceinline__ void split_f16(float x, float lscale, _Float16& h, _F
     l = (_Float16)((xc - (float)h) * lscale);
 }
 
-// n / d by a host-made reciprocal (rcp = floor(2^32 / d) + 1; exact while n * d < 2^32; d <= 1 passes n through)
-__device__ __forceinline__ int fdiv(int n, int d, unsigned int rcp) { return d <= 1 ? n : (int)__umulhi((unsigned int)n, rcp); }
+// n / d by a host-made reciprocal (rcp = floor(2^32 / d) + 1; exact while n * d < 2^32).  rcp == 0 (wave-uniform) means "divide":
+// d <= 1, or a launch whose quotients could leave that range (the launcher decides, gemm_p16.hip rcp32)
+__device__ __forceinline__ int fdiv(int n, int d, unsigned int rcp) { return rcp ? (int)__umulhi((unsigned int)n, rcp) : (d <= 1 ? n : n / d); }
 
 // Range guard of the fp16 split: an operand beyond +-65504 saturates (h clamps), which the caller must learn about.  Producers
 // OR their lanes' findings into a register and raise the sticky flag once per thread (atomics only on the rare bad path).

@@ -576,16 +576,17 @@ static unsigned int rcp32(int d) { return d <= 1 ? 0u : (unsigned int)((1ull << 
 
 hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
-    {   // reciprocals for the kernel's index arithmetic (kernels.h); exactness needs n * d < 2^32 for every quotient taken
-        const long long Mp = (long long)a.B * a.T_out + 256;
-        if (a.B <= 0 || a.T_out <= 0 || a.N <= 0 || Mp * a.T_out >= (1ll << 32) || Mp * 64 >= (1ll << 32)) return hipErrorInvalidValue;
-        a.rcp_T_out = rcp32(a.T_out);
-        a.rcp_ntiles = rcp32((a.N + GEMM_BN - 1) / GEMM_BN);
+    {   // reciprocals for the kernel's index arithmetic (kernels.h); exactness needs n * d < 2^32 for every quotient taken:
+        // numerators are rows (< M + 256), columns (< N + 128) or tile counts; a launch beyond that divides (rcp = 0)
+        if (a.B <= 0 || a.T_out <= 0 || a.N <= 0) return hipErrorInvalidValue;
+        const long long Mp = (long long)a.B * a.T_out + 256, Np = (long long)a.N + 128;
         a.gn_cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;
         a.gnr_cpg = a.gnr_groups > 0 ? a.N / a.gnr_groups : 0;
-        a.rcp_gn_cpg = rcp32(a.gn_cpg);
-        a.rcp_gnr_cpg = rcp32(a.gnr_cpg);
-        a.rcp_gnr_R = rcp32(a.gnr_tile_rows);
+        a.rcp_T_out = Mp * a.T_out < (1ll << 32) ? rcp32(a.T_out) : 0u;
+        a.rcp_ntiles = Mp * Np < (1ll << 32) ? rcp32((a.N + GEMM_BN - 1) / GEMM_BN) : 0u;
+        a.rcp_gn_cpg = Np * Np < (1ll << 32) ? rcp32(a.gn_cpg) : 0u;
+        a.rcp_gnr_cpg = Np * Np < (1ll << 32) ? rcp32(a.gnr_cpg) : 0u;
+        a.rcp_gnr_R = Mp * 64 < (1ll << 32) && a.gnr_tile_rows <= 64 ? rcp32(a.gnr_tile_rows) : 0u;
     }
     // shape contract (the kernel indexes without further checks)
     const int kq = a.half16 ? 64 : GEMM_BK, ew = a.half16 ? 1 : 2;      // k elements per 128-byte line; halves per element
