@@ -226,7 +226,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         __syncthreads();
         if (kt + 1 < ntiles) fetch((kt + 1) * AT_K);
 
-        // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys (A = K fragment: lane (key, h) holds K[key][16kb + 8h + j])
+        // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys (A = K fragment: lane (key, h) holds K[key][16kb + 8h + j]).
+        // (Skipping the second sub-tile of a last tile with <= 32 keys -- T = 322 leaves two -- measured SLOWER, 3.20 vs 3.02 ms of
+        // attention per step: the uniform branches break the MFMA / LDS interleaving of the unrolled body.)
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -370,7 +372,10 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const long blocks128 = (long)b128 * a.H * a.B;
     const double waste128 = 1.0 - (double)a.T / (b128 * 128.0);
     static const int env_nw = [] { const char* e = getenv("MTTS_ATTN_NW"); return e ? atoi(e) : 0; }();     // A/B runs only
-    const bool use128 = env_nw == 4 || (env_nw == 0 && blocks128 >= 768 && waste128 < 0.1);
+    // (or when 64-query blocks would pad to the same row count anyway -- T = 322: 3 x 128 = 6 x 64 -- and the grid still has
+    // two workgroups per CU: half as many workgroups re-stage each head's keys and values)
+    const bool same_rows = b128 * 128 == b64 * 64 && blocks128 >= 512;
+    const bool use128 = env_nw == 4 || (env_nw == 0 && ((blocks128 >= 768 && waste128 < 0.1) || same_rows));
     if (use128) {
         if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
