@@ -46,6 +46,12 @@ __device__ __forceinline__ float sin_sq_hw(float y) {
     const float t = __builtin_amdgcn_fractf(y * 0.31830988618379067154f);     // 2y / (2 pi), reduced to [0, 1)
     return fmaf(-0.5f, __builtin_amdgcn_cosf(t), 0.5f);
 }
+// x + s1 sin(s0 x)^2 with the identity folded in: (x + s1/2) - (s1/2) cos(2 s0 x) -- an add and an FMA behind the cosine instead of
+// FMA, multiply, add (the epilogue of the FeedForward's first projection is vector-issue bound: DESIGN.md section 5)
+__device__ __forceinline__ float snake_hw(float x, float s0, float s1_half) {
+    const float t = __builtin_amdgcn_fractf((x * s0) * 0.31830988618379067154f);
+    return __builtin_fmaf(-s1_half, __builtin_amdgcn_cosf(t), x + s1_half);
+}
 __device__ __forceinline__ float sin_sq_poly(float y);
 __device__ __forceinline__ float sin_sq(float y) {
 #ifdef MTTS_SNAKE_POLY

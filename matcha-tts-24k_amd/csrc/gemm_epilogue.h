@@ -430,6 +430,7 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias[2] = {cols.bias[0], cols.bias[1]}, s0[2] = {cols.s0[0], cols.s0[1]}, s1[2] = {cols.s1[0], cols.s1[1]},
                 ws[2] = {cols.ws[0], cols.ws[1]};
+    [[maybe_unused]] const f32x4 s1h[2] = {cols.s1[0] * 0.5f, cols.s1[1] * 0.5f};
     // the arguments the passes use, pinned in SGPRs
     // (the empty asm makes each an SGPR value the compiler cannot re-load; a laundered pointer is generic, so it is cast back
     // to the global address space: flat stores would also tick lgkmcnt)
@@ -567,10 +568,13 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
                     o[0] += *reinterpret_cast<const f32x4*>(q2);
                     o[1] += *reinterpret_cast<const f32x4*>(q2 + 4);
                 }
-                if constexpr (LN) {
+                if constexpr (LN) {      // rstd (x.W' - mean rowsum(W')) + bias as two FMAs per element: x.W' rstd + (bias - mean rstd rowsum)
                     const float mean = srow[wm * (BM / 2) + rl], rstd = srow[BM + wm * (BM / 2) + rl];
-                    o[0] = (o[0] - mean * ws[0]) * rstd + bias[0];
-                    o[1] = (o[1] - mean * ws[1]) * rstd + bias[1];
+                    const float nmr = -(mean * rstd);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[h][e] = __builtin_fmaf(o[h][e], rstd, __builtin_fmaf(nmr, ws[h][e], bias[h][e]));
                 } else {
                     o[0] += bias[0];
                     o[1] += bias[1];
@@ -593,7 +597,13 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
                 for (int h = 0; h < 2; ++h) {
                     if constexpr (ACT == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[h][e] = o[h][e] + s1[h][e] * sin_sq(o[h][e] * s0[h][e]);     // SnakeBeta
+                        for (int e = 0; e < 4; ++e) {                                                          // SnakeBeta
+#ifdef MTTS_SNAKE_POLY
+                            o[h][e] = o[h][e] + s1[h][e] * sin_sq(o[h][e] * s0[h][e]);
+#else
+                            o[h][e] = snake_hw(o[h][e], s0[h][e], s1h[h][e]);
+#endif
+                        }
                     } else if constexpr (ACT == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[h][e] = act_apply(o[h][e], p.act, s0[h][e], s1[h][e]);
