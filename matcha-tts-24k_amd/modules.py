@@ -197,8 +197,10 @@ class CFM(nn.Module):
         if self.graph_mode == "0" or not self.fold_padding:
             return False
         # auto: few utterances (the host's launch cost is what a graph saves; the kernels take the same time) and few enough
-        # (B, bucket) combinations that captures (~15 ms each, first use only) stay rare
-        return self.graph_mode == "1" or (B <= 8 and B * self._graph_rows(y_max) <= self.graph_max_rows)
+        # (B, bucket) combinations that captures (~15 ms each, first use only) stay rare.  The row bucket pads each utterance
+        # (322 -> 384 rows): free at B <= 4 (14.7 ms per step either way at B = 1), 6 % of GPU time at B = 8 (16.6 vs 15.7 ms,
+        # profiles/r02d_small_batch.log) -- beyond four utterances the direct launches are the faster path
+        return self.graph_mode == "1" or (B <= 4 and B * self._graph_rows(y_max) <= self.graph_max_rows)
 
     def _solve_on_graph(self, hip, mu, z, n_timesteps, t_out, out_scale, out_shift, t_len, y_lengths, y_max):
         """One ODE solve as ONE graph launch: the ~100 kernels per evaluation are captured once per (batch, row bucket, solver,
