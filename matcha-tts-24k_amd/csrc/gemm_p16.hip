@@ -433,8 +433,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
         for (int t = 0; t < D && t < nk; ++t) issue(t);
 #if MTTS_EPI_PRE == 2
         // the residual image tile of a 64-row tile: requested right behind the first D tiles; its R loads sit in the
-        // vector-memory counter between tile D-1 and tile D, so the first D counted waits allow R more (loads retire in order)
+        // vector-memory counter between tile D-1 and tile D, so the first D counted waits allow R more (loads retire in order).
+        // The counts depend on that ORDER: the empty asm statements keep the compiler from moving these plain loads across the
+        // tile requests on either side (they do not alias the LDS writes, so it otherwise may).
+        asm volatile("" ::: "memory");
         if (epi_wave) epi_prefetch<BM, EPI_PASS>(p, pre, M, m0, n0, wm, wn, lane, epi_row0);
+        asm volatile("" ::: "memory");
 #endif
         const int pre_r = (BM == 64 && MTTS_EPI_PRE == 2 && pre.valid) ? (p.half16 ? EPI_PASS : 2 * EPI_PASS) : 0;
         ln_stats();
