@@ -215,6 +215,7 @@ def time_freqs(dim: int) -> torch.Tensor:
 
 class HipModel:
     """One mtts_ctx: packed weights on a device + cached workspaces + the path's entry points on torch tensors."""
+    _uids = 0
 
     def __init__(self, hp: PathHParams, terms: Optional[int] = None):
         """``terms``: GEMM arithmetic (mtts_set_arithmetic); None = the library default (fp16 two-term split, MTTS_GEMM_TERMS)."""
@@ -239,6 +240,9 @@ class HipModel:
         if terms is not None:
             check(self.lib.mtts_set_arithmetic(self.ctx, int(terms)))
         self.weights: Optional[torch.Tensor] = None
+        HipModel._uids += 1
+        self.uid = HipModel._uids    # unique per process (id() is re-used after garbage collection)
+        self.generation = 0          # bumped by every load_state_dict: whatever captured the weights' address is stale afterwards
         self.device: Optional[torch.device] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._last_ws: Dict[str, torch.Tensor] = {}     # workspace of the latest call per kind: its first word = range flag
@@ -283,6 +287,7 @@ class HipModel:
         self.weights = torch.empty(nbytes, dtype=torch.uint8, device=device)
         check(self.lib.mtts_upload_weights(self.ctx, self.weights.data_ptr(), nbytes))
         self.device = device
+        self.generation += 1
         self._ws.clear()
         self._last_ws.clear()
 

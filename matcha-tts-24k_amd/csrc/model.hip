@@ -1176,6 +1176,10 @@ int mtts_cfm_solve_folded(mtts_ctx* c, const float* d_x0, const float* d_mu, con
         return -1;
     }
     if (y_max >= T) { set_error("mtts_cfm_solve_folded: no padded frame to fold (y_max >= T)"); return -1; }
+    if (T_fold % (1 << (c->cfg.dec_levels - 1))) {      // (plan_decoder halves the row count per level: a remainder would truncate)
+        set_error("mtts_cfm_solve_folded: T_fold must be a multiple of 2^(levels-1) (mtts_fold_rows returns such counts)");
+        return -1;
+    }
     return solve_core(c, d_x0, d_mu, nullptr, d_y_lengths, add_mu, h_t_span, n_steps, solver, B, T, T_fold, d_out, T_out, out_scale,
                       out_shift, d_ws, ws_bytes, stream);
 }

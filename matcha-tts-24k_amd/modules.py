@@ -210,7 +210,13 @@ class CFM(nn.Module):
         f = 2 ** (len(self._rt.hp.decoder.channels) - 1)
         y_cap = (rows // f - 1) * f                       # the longest valid length these rows can hold
         t_src = 2 * rows                                  # source row stride: >= any T_pad whose valid length fits
-        key = (B, rows, self.solver, int(n_timesteps), float(out_scale), float(out_shift), bool(self.use_mu_prior), hip.gemm_terms())
+        # A captured graph bakes device pointers into its kernel nodes: the context's packed weights above all.  The key names
+        # the context AND the generation of its weights (HipModel.load_state_dict bumps it), and graphs of an older generation
+        # are dropped before the lookup: after model.load_state_dict / .to() they would read freed memory.
+        gen = (hip.uid, hip.generation)
+        for k in [k for k in self._graphs if k[0] == gen[0] and k[1] != gen[1]]:
+            del self._graphs[k]
+        key = gen + (B, rows, self.solver, int(n_timesteps), float(out_scale), float(out_shift), bool(self.use_mu_prior), hip.gemm_terms())
         e = self._graphs.get(key)
         if e is None:
             dev = mu.device

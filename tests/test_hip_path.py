@@ -480,6 +480,29 @@ def test_graph_replay_equals_direct_launches(prod, tiny, synthetic, dev):
             dec.graph_mode = keep
 
 
+def test_graph_cache_follows_weight_reload(hparams, synthetic, dev):
+    """A captured graph bakes the packed weights' address into its kernel nodes.  Loading another state dict into a model that
+    has already replayed a graph must not replay the old one (round-2 advisor finding): the second synthesis equals a fresh
+    model's with the new weights, differs from the first, and the stale graph has left the cache."""
+    hp = hparams.tiny(n_spks=2)
+    sd_a, sd_b = synthetic.make_state_dict(hp, seed=7), synthetic.make_state_dict(hp, seed=8)
+    model = make_model(hp, sd_a, dev)
+    dec = model.decoder
+    dec.graph_mode = "1"
+    x, x_len, spk = synthetic.make_inputs(hp, 1, 12, seed=5, lengths=[12])
+    args = (x.to(dev), x_len.to(dev), 2)
+    first = model.synthesise(*args, speaker=spk.to(dev))["mel"].clone()
+    assert dec.graph_replays == 1 and len(dec._graphs) == 1
+    model.load_state_dict(sd_b, strict=True)
+    second = model.synthesise(*args, speaker=spk.to(dev))["mel"].clone()
+    assert dec.graph_replays == 2 and len(dec._graphs) == 1      # a new capture replaced the stale graph
+    fresh = make_model(hp, sd_b, dev)
+    fresh.decoder.graph_mode = "0"
+    want = fresh.synthesise(*args, speaker=spk.to(dev))["mel"]
+    assert maxabs(second, want) < 5e-5
+    assert maxabs(second, first) > 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ 16-bit storage mode (config #3)
 def _half_model(hp, sd, dev, monkeypatch):
     monkeypatch.setenv("MTTS_GEMM_TERMS", "16")
