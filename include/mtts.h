@@ -201,6 +201,29 @@ int mtts_attention_f32(const float* d_qkv, const float* d_mask, int B, int T, in
 int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, int H, int D, float scale, int mask_mode,
                        float* d_out, void* d_scratch, void* stream);
 
+/* Transformer-block chain (csrc/tblock_chain.hip): the row-local part of a BasicTransformerBlock behind the attention as ONE
+ * launch -- x1 = x + att . W_out^T + b_out (reference transformer.py:261); x2 = x1 + W2 . SnakeBeta(W1' . LN(x1) + b1') + b2
+ * (transformer.py:278-301, FeedForward :104-120, SnakeBeta :61-77); qkv = W_qkv' . LN(x2) + b_qkv' (the following block's
+ * norm1 + to_q/k/v, transformer.py:249-258).  LN = LayerNorm without affine (eps 1e-5): the caller folds gamma / beta into the
+ * primed panels, as the model's packer does.  Rows are independent; att [M][inner], x [M][C] fp32 on the device; the panels
+ * ([N][K] row major), biases and SnakeBeta constants (p0 = exp(alpha), p1 = 1 / (exp(beta) + 1e-9), [4C]) on the HOST -- this
+ * test entry packs the fragment stream itself.  C in {128, 256, 384}, inner % 32 == 0 (0: FeedForward only), h_w_qkv NULL: no
+ * q|k|v phase.  d_out_mask [M] (0/1) or NULL multiplies the rows of x_out (the masked image convs read).  qb: rows per
+ * workgroup (64 / 48 / 32), ch: hidden chunk (128; 256 with C = 384, qb 48 / 32).  Outputs: x_out [M][C], qkv_out [M][n_qkv]. */
+/* Host-only: the fragment stream of a chain (no device needed).  Per wave (8): [out-projection: inner/32 k-steps x C/128 tiles]
+ * [per hidden chunk of ch: C/32 k-steps x ch/128 tiles of w1, then ch/32 k-steps x C/128 tiles of w2][q|k|v passes: C/32 k-steps x
+ * C/128 tiles] + ring padding; a tile = the fp16 head fragment then the 2^11-scaled residual fragment, a fragment = 64 lanes x 8
+ * halves with lane (r = lane & 15, q = lane >> 4) holding panel row n0 + r, columns k0 + 8 q .. + 7 (the A operand of
+ * v_mfma_f32_16x16x32_f16).  h_dst: mtts_chain_stream_frags(...) * 8 * 512 halves. */
+int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv);
+int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
+                           const float* h_w_qkv, uint16_t* h_dst);
+int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch);
+int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                      const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,
+                      const float* h_b2, const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb,
+                      int ch, float* d_x_out, float* d_qkv_out, void* d_scratch, void* stream);
+
 /* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
 int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);
 

@@ -19,7 +19,7 @@ from .hparams import PathHParams
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = Path(os.environ["MTTS_HIP_LIB"]) if os.environ.get("MTTS_HIP_LIB") else HERE / "libmtts_hip.so"   # override: A/B of two builds
-SOURCES = ["gemm_f32.hip", "attention_f32.hip", "gemm_p16.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
+SOURCES = ["gemm_f32.hip", "attention_f32.hip", "gemm_p16.hip", "tblock_chain.hip", "norm_glue.hip", "vocos.hip", "model.hip"]
 HEADERS = [CSRC / "kernels.h", CSRC / "device_utils.h", CSRC / "model.h", HERE.parent / "include" / "mtts.h"]
 SOLVERS = {"euler": 0, "midpoint": 1, "rk4": 2}
 
@@ -148,6 +148,10 @@ def load() -> C.CDLL:
         "mtts_gemm_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp,
                                 i32, vp, f32, vp, i32, vp, i32, vp]),
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
+        "mtts_chain_stream_frags": (i64, [i32, i32, i32, i32]),
+        "mtts_chain_stream_pack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "mtts_tblock_chain_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
+        "mtts_tblock_chain": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_channel_layernorm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
@@ -517,6 +521,35 @@ def gemm_p16(a, w, bias=None, *, B, T_in, T_out=None, tap_off=None, in_stride=1,
                             res.shape[1] if res is not None else 0, ptr(out_mask), float(out_scale), ptr(out), N,
                             ptr(out16), float(lscale), ptr(stats), force_bm, scratch.data_ptr(), stream_ptr()))
     return {"out": out, "out16": out16, "stats": stats}
+
+
+def _host(t):
+    """Host fp32 array of a tensor (or None) and the pointer ctypes passes for it."""
+    if t is None:
+        return None, None
+    a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+    return a, a.ctypes.data
+
+
+def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv=None, out_mask=None, qb=64, ch=128):
+    """Row-local chain of a transformer block (csrc/tblock_chain.hip, include/mtts.h mtts_tblock_chain).  att [M, inner] (or None:
+    FeedForward only), x [M, C] on the device; panels / vectors anywhere (copied to the host).  Returns (x_out, qkv or None)."""
+    lib = load()
+    M, Cc = x.shape
+    inner = att.shape[1] if att is not None else 0
+    n_qkv = w_qkv.shape[0] if w_qkv is not None else 0
+    n = lib.mtts_tblock_chain_scratch_bytes(M, Cc, inner, n_qkv, ch)
+    if n < 0:
+        raise RuntimeError("mtts_tblock_chain: unsupported shape")
+    scratch = torch.empty(n, dtype=torch.uint8, device=x.device)
+    x_out = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+    qkv = torch.empty(M, n_qkv, dtype=torch.float32, device=x.device) if n_qkv else None
+    keep = [_host(t) for t in (w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv, b_qkv)]
+    hp = [k[1] for k in keep]
+    check(lib.mtts_tblock_chain(ptr(att), ptr(x), M, Cc, inner, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
+                                n_qkv, ptr(out_mask), qb, ch, ptr(x_out), ptr(qkv), scratch.data_ptr(), stream_ptr()))
+    torch.cuda.synchronize()
+    return x_out, qkv
 
 
 def attention_f32(qkv, mask, B, T, H, D, scale, mask_mode):

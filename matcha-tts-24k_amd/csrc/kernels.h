@@ -158,6 +158,58 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
 static inline double attn_bytes(const AttnArgs& a) { return 4.0 * double(a.B) * a.T * 4.0 * a.H * a.D; }
 
+// ---- transformer-block chain (tblock_chain.hip): the row-local part of a BasicTransformerBlock as ONE launch.
+// Behind the attention everything up to the next attention is row-local (reference transformer.py:261-301): out-projection +
+// residual, LayerNorm, FeedForward (Linear - SnakeBeta - Linear) + residual and, when another block follows, its LayerNorm'd
+// q|k|v projection.  A workgroup (8 waves) keeps QB rows of the residual stream in LDS for the whole chain and streams the
+// weights from L2 straight into registers: they are stored as "fragment streams" (chain_stream_*), per wave the 1 KiB MFMA
+// operand fragments in exactly the order the wave consumes them, so every load is one coalesced global_load_dwordx4 per lane
+// and a register ring keeps ~12 KiB per wave in flight.  Neither the attention output tile, the 4C-wide hidden layer nor the
+// LayerNorm moments touch HBM between the phases.  Arithmetic: the fp16 two-term split of gemm_p16.hip (three MFMAs per MAC).
+constexpr int CHAIN_WAVES = 8;           // waves per workgroup of the chain kernel = per-wave streams in a fragment stream
+struct ChainArgs {
+    int M = 0;                           // rows (B * T): rows are independent, a workgroup takes QB consecutive ones
+    int C = 0;                           // width of the residual stream (128, 256 or 384)
+    int inner = 0;                       // attention width (heads * 64) = K of the out-projection; 0: no out-projection phase
+    const _Float16* att16 = nullptr;     // P16 image of the attention output [M][ld_att halves]
+    int ld_att = 0;
+    const _Float16* x16 = nullptr;       // P16 image of the residual stream x [M][ld_x halves] (the residual; FF input when inner == 0)
+    int ld_x = 0;
+    const _Float16* wstream = nullptr;   // fragment stream of the whole chain (chain_stream_pack), [8 waves][frags][64 lanes][8 halves]
+    long stream_frags = 0;               // fragments per wave incl. the tail padding
+    const float* b_out = nullptr;        // [C]
+    const float* b1 = nullptr;           // [4C]  FF first projection: bias with the LayerNorm shift folded in
+    const float* wsum1 = nullptr;        // [4C]  row sums of the folded panel (LayerNorm applied after the product)
+    const float* p0 = nullptr;           // [4C]  SnakeBeta exp(alpha)
+    const float* p1 = nullptr;           // [4C]  SnakeBeta 1 / (exp(beta) + 1e-9)
+    const float* b2 = nullptr;           // [C]
+    const float* b_qkv = nullptr;        // [3 * inner] or null: no q|k|v phase
+    const float* wsum_qkv = nullptr;
+    int n_qkv = 0;                       // 3 * inner
+    _Float16* x_out = nullptr;           // P16 image of the block's output rows [M][ld_out halves] (may alias x16)
+    int ld_out = 0;
+    const float* x_out_mask = nullptr;   // [M] or null: rows of x_out are multiplied by it (0 / 1): the masked copy convs read
+    _Float16* qkv16 = nullptr;           // P16 image (unscaled residuals) of the next block's q|k|v [M][ld_qkv halves]
+    int ld_qkv = 0;
+    float eps = 1e-5f;
+    unsigned int* range_flag = nullptr;
+    int qb = 0, ch = 0;                  // rows per workgroup (64 / 48 / 32) and hidden chunk (128 / 256) the stream was packed for
+};
+// fragments per wave of the stream for (C, inner, hidden chunk, q|k|v width), incl. the padding the register ring may run into
+long chain_stream_frags(int C, int inner, int ch, int n_qkv);
+// Host packing from the fp32 panels ([N][K] row-major, K contiguous): w_out [C][inner], w1 [4C][C], w2 [C][4C], w_qkv [n_qkv][C];
+// null panels leave their phase out.  dst: chain_stream_frags(...) * 8 * 512 halves.
+void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, const float* w1, const float* w2, const float* w_qkv,
+                       uint16_t* dst, bool* saturates);
+bool chain_supported(int C, int inner, int n_qkv);
+hipError_t launch_tblock_chain(const ChainArgs& a, hipStream_t s);
+static inline double chain_flops(const ChainArgs& a) {
+    return 2.0 * double(a.M) * (double(a.C) * a.inner + 8.0 * double(a.C) * a.C + double(a.C) * a.n_qkv);
+}
+static inline double chain_bytes(const ChainArgs& a) {
+    return 4.0 * (double(a.M) * (a.inner + 2.0 * a.C + a.n_qkv) + double(a.C) * a.inner + 8.0 * double(a.C) * a.C + double(a.C) * a.n_qkv);
+}
+
 // ---- normalisation / activation / glue (norm_glue.hip)
 hipError_t launch_row_stats(const float* x, int M, int C, int ld, float eps, float* mean, float* rstd, hipStream_t s);
 

@@ -34,6 +34,13 @@ struct ResnetW {
 struct TBlockW {
     Panel qkv, out, ff1, ff2;  // LayerNorm affines folded into qkv / ff1
     Vec alpha_exp, inv_beta;
+    // fragment stream of the block's row-local chain (kernels.h ChainArgs; tblock_chain.hip): out-projection, FeedForward and --
+    // when another block of the same run follows -- that block's q|k|v projection.  0 frags = chain not packed for this block.
+    size_t chain = 0;          // offset in the image (floats)
+    long chain_frags = 0;
+    int chain_ch = 0;          // hidden chunk the stream was packed for
+    int chain_nqkv = 0;        // width of the q|k|v part (0: none)
+    int next = -1;             // index of the block whose q|k|v the chain computes
 };
 struct DecW {
     Vec freqs;
@@ -87,6 +94,10 @@ struct mtts_ctx {
     bool half_now = false;        // set while the estimator's launches are being enqueued in that mode
     bool fast16 = false;          // MTTS_GEMM_TERMS=1 at mtts_create: the estimator's P16 kernels multiply the fp16 heads only
     bool p16_on = true;           // fp16-split mode: activations as P16 images between kernels (MTTS_P16=0 at mtts_create disables)
+    bool chain_on = true;         // transformer blocks' row-local part as one launch (tblock_chain.hip; MTTS_CHAIN=0 at mtts_create disables)
+    int chain_ch = 128;           // hidden chunk of the chain's FeedForward (MTTS_CHAIN_CH at mtts_create: 128 / 256)
+    int chain_qb = 0;             // rows per workgroup (MTTS_CHAIN_QB at mtts_create; 0 = by shape)
+    int chain_min_rows = 4096;    // estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS)
     mtts::DecW dec;
     mtts::EncW enc;
     // profiling

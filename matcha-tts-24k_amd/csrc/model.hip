@@ -68,6 +68,12 @@ static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
+static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
+    ChainArgs a = a0;
+    a.range_flag = c->cur_flag;
+    LAUNCHB(c, 0, chain_flops(a), chain_bytes(a), s, launch_tblock_chain(a, s));
+    return 0;
+}
 static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
     GnApplyArgs a = a0;
     a.range_flag = c->cur_flag;
@@ -391,6 +397,25 @@ static int pack_all(mtts_ctx* c) {
         if (P.ok) P.add_planes(p);
         D.tmlp = p;
     }
+    // fragment streams of the transformer blocks' row-local chains (tblock_chain.hip): fp16-split arithmetic, P16 flow only
+    if (P.ok && c->chain_on && c->gemm_terms == 2 && !c->half16 && !c->fast16 && c->p16_on && g.dec_head_dim == 64) {
+        const int nb = g.dec_n_blocks;
+        for (size_t k = 0; k < D.tb.size(); ++k) {
+            TBlockW& t = D.tb[k];
+            const int C = t.out.N, nq = ((int)(k % nb) + 1 < nb) ? D.tb[k + 1].qkv.N : 0;
+            const int ch = (C == 384 && c->chain_ch == 256) ? 256 : 128;
+            if (!chain_supported(C, inner, nq) || t.ff1.N != 4 * C || t.ff1.ktap != C || t.ff2.ktap != 4 * C || t.out.ktap != inner) continue;
+            if (nq && D.tb[k + 1].qkv.ktap != C) continue;
+            t.chain_frags = chain_stream_frags(C, inner, ch, nq);
+            t.chain_ch = ch;
+            t.chain_nqkv = nq;
+            t.next = nq ? (int)k + 1 : -1;
+            t.chain = P.alloc((size_t)t.chain_frags * CHAIN_WAVES * 256);
+            chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
+                              nq ? &c->image[D.tb[k + 1].qkv.w] : nullptr, reinterpret_cast<uint16_t*>(&c->image[t.chain]),
+                              &c->weights_saturate);
+        }
+    }
     if (!P.ok) { set_error(P.why); return -1; }
     c->packed = true;
     return 0;
@@ -454,6 +479,7 @@ struct DecBufs {
     const int* ne(int l) const { return folded ? nextra[l] : nullptr; }
     const float* kb(int l) const { return folded ? kbias[l] : mask[l]; }
     bool tables = false;
+    bool qkv_ready = false;              // the previous block's chain launch already left this block's q|k|v image in QKV
 };
 
 // Transformer blocks of width C run on P16 images (gemm_p16.hip, attention P16 I/O) when the context computes in the
@@ -607,16 +633,44 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         _Float16* QKV16 = reinterpret_cast<_Float16*>(d.QKV);
         _Float16* ATT16 = reinterpret_cast<_Float16*>(d.ATT);
         _Float16* FF16 = reinterpret_cast<_Float16*>(d.FF);
-        GemmArgs q;
-        panel_args(c, t.qkv, q); rows_plain(q, B, T);
-        q.a16_0 = d.X16; q.lda16_0 = d.ew * C; q.c0 = C; q.a_part = d.lnp; q.a_nparts = C / 64;
-        q.out16 = QKV16; q.ld16 = 3 * d.ew * inner; q.out_lscale = 1.0f;
-        RET_IF(run_gemm(c, q, s));
+        // the row-local part as one launch (tblock_chain.hip) when the stream was packed and the batch is large enough that a
+        // workgroup per QB rows fills the chip: every workgroup streams ALL of the chain's weights (~7 MB at width 384), which
+        // only pays when their cost is shared by many rows per CU
+        const bool chain = t.chain_frags > 0 && d.p16 && !c->half_now && M >= c->chain_min_rows && (emit_stats ? t.chain_nqkv > 0 : true);
+        if (!d.qkv_ready) {
+            GemmArgs q;
+            panel_args(c, t.qkv, q); rows_plain(q, B, T);
+            q.a16_0 = d.X16; q.lda16_0 = d.ew * C; q.c0 = C; q.a_part = d.lnp; q.a_nparts = C / 64;
+            q.out16 = QKV16; q.ld16 = 3 * d.ew * inner; q.out_lscale = 1.0f;
+            RET_IF(run_gemm(c, q, s));
+        }
+        d.qkv_ready = false;
         AttnArgs at;
         at.qkv16 = QKV16; at.ld16 = 3 * d.ew * inner; at.out16 = ATT16; at.ldo16 = d.ew * inner; at.mask = d.kb(lvl);
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
         at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.klen = d.nr(lvl); at.fast16 = c->fast16;
         RET_IF(run_attn(c, at, s));
+        if (chain) {
+            ChainArgs a;
+            a.M = M; a.C = C; a.inner = inner;
+            a.att16 = ATT16; a.ld_att = 2 * inner;
+            a.x16 = d.X16; a.ld_x = 2 * C;
+            a.wstream = reinterpret_cast<const _Float16*>(W(c, t.chain)); a.stream_frags = t.chain_frags;
+            a.b_out = W(c, t.out.b); a.b1 = W(c, t.ff1.b); a.wsum1 = W(c, t.ff1.wsum);
+            a.p0 = W(c, t.alpha_exp.off); a.p1 = W(c, t.inv_beta.off); a.b2 = W(c, t.ff2.b);
+            if (emit_stats) {                 // another block follows: its q|k|v leaves this launch, x stays unmasked
+                const TBlockW& nx = c->dec.tb[t.next];
+                a.b_qkv = W(c, nx.qkv.b); a.wsum_qkv = W(c, nx.qkv.wsum); a.n_qkv = nx.qkv.N;
+                a.qkv16 = QKV16; a.ld_qkv = 2 * nx.qkv.N;
+                a.x_out = d.X16; a.ld_out = 2 * C;
+                d.qkv_ready = true;
+            } else if (last16) { a.x_out = last16; a.ld_out = 2 * C; a.x_out_mask = d.mask[lvl]; }
+            else { a.x_out = d.X16; a.ld_out = 2 * C; }
+            a.ch = t.chain_ch;
+            a.qb = c->chain_qb ? c->chain_qb : (a.ch == 256 ? (M >= 8192 ? 48 : 32) : (M >= 8192 ? 64 : 32));
+            RET_IF(run_chain(c, a, s));
+            return 0;
+        }
         GemmArgs o;
         panel_args(c, t.out, o); rows_plain(o, B, T);
         o.a16_0 = ATT16; o.lda16_0 = d.ew * inner; o.c0 = inner;
@@ -997,6 +1051,10 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     c->gemm_terms = default_gemm_terms();
     { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; c->half16 = e && atoi(e) == 16; }   // 1 / 16: fp16 modes (include/mtts.h)
     { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
+    { const char* e = getenv("MTTS_CHAIN"); c->chain_on = !(e && e[0] == '0'); }
+    { const char* e = getenv("MTTS_CHAIN_CH"); c->chain_ch = (e && atoi(e) == 256) ? 256 : 128; }
+    { const char* e = getenv("MTTS_CHAIN_QB"); c->chain_qb = e ? atoi(e) : 0; }
+    { const char* e = getenv("MTTS_CHAIN_MIN_ROWS"); if (e) c->chain_min_rows = atoi(e); }
     return c;
 }
 
@@ -1495,6 +1553,80 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
     a.y = d_y; a.partial = static_cast<const float*>(d_scratch); a.gamma = d_gamma; a.beta = d_beta; a.mask = d_mask;
     a.out = d_out; a.B = B; a.T = T; a.C = C; a.G = G; a.eps = eps;
     HIP_OK(launch_gn_apply(a, s));
+    return 0;
+}
+
+// Test entry for the transformer-block chain (tblock_chain.hip).  fp32 operands are converted to P16 images in d_scratch, the fp32
+// panels (LayerNorm affines already folded: w1 / b1 for the FeedForward, w_qkv / b_qkv for the following block) are packed into a
+// fragment stream on the host, and the P16 outputs are decoded back to fp32.  w_qkv == NULL: no q|k|v phase; inner == 0: no
+// out-projection (the FeedForward alone on d_x).  h_* pointers are HOST memory, d_* device memory.
+int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv) {
+    if (!chain_supported(C, inner, n_qkv) || (ch != 128 && ch != 256)) { set_error("mtts_chain_stream_frags: unsupported shape"); return -1; }
+    return chain_stream_frags(C, inner, ch, n_qkv);
+}
+int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
+                           const float* h_w_qkv, uint16_t* h_dst) {
+    if (!chain_supported(C, inner, n_qkv) || (ch != 128 && ch != 256) || !h_w1 || !h_w2 || !h_dst || (inner && !h_w_out) || (n_qkv && !h_w_qkv)) {
+        set_error("mtts_chain_stream_pack: unsupported shape or null panel");
+        return -1;
+    }
+    chain_stream_pack(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, h_dst, nullptr);
+    return 0;
+}
+int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch) {
+    if (!chain_supported(C, inner, n_qkv)) return -1;
+    const int64_t stream = (int64_t)chain_stream_frags(C, inner, ch, n_qkv) * CHAIN_WAVES * 1024;
+    return stream + (int64_t)M * 4 * (inner + 2 * C + n_qkv) + 4 * (int64_t)(2 * n_qkv + 18 * C) + 4096;
+}
+int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                      const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
+                      const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
+                      float* d_qkv_out, void* d_scratch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h_w_qkv) n_qkv = 0;
+    if (!chain_supported(C, inner, n_qkv) || !d_x || !h_w1 || !h_w2 || !d_scratch || !d_x_out) { set_error("mtts_tblock_chain: unsupported shape or null buffer"); return -1; }
+    const long frags = chain_stream_frags(C, inner, ch, n_qkv);
+    std::vector<uint16_t> hs((size_t)frags * CHAIN_WAVES * 512);
+    chain_stream_pack(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, hs.data(), nullptr);
+    std::vector<float> hc((size_t)18 * C + 2 * (size_t)n_qkv, 0.f);         // wsum1 | b1 | p0 | p1 | b_out | b2 | wsum_qkv | b_qkv
+    for (int n = 0; n < 4 * C; ++n) {
+        double a = 0.0;
+        for (int k = 0; k < C; ++k) a += (double)h_w1[(size_t)n * C + k];
+        hc[n] = (float)a;
+        hc[4 * C + n] = h_b1 ? h_b1[n] : 0.f;
+        hc[8 * C + n] = h_p0[n];
+        hc[12 * C + n] = h_p1[n];
+    }
+    for (int n = 0; n < C; ++n) { hc[16 * C + n] = (inner && h_b_out) ? h_b_out[n] : 0.f; hc[17 * C + n] = h_b2 ? h_b2[n] : 0.f; }
+    for (int n = 0; n < n_qkv; ++n) {
+        double a = 0.0;
+        for (int k = 0; k < C; ++k) a += (double)h_w_qkv[(size_t)n * C + k];
+        hc[18 * C + n] = (float)a;
+        hc[18 * C + n_qkv + n] = h_b_qkv ? h_b_qkv[n] : 0.f;
+    }
+    char* sc = static_cast<char*>(d_scratch);
+    _Float16* d_stream = reinterpret_cast<_Float16*>(sc); sc += hs.size() * 2;
+    float* d_c = reinterpret_cast<float*>(sc); sc += hc.size() * 4;
+    sc = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(sc) + 255) & ~uintptr_t(255));
+    _Float16* att16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * inner * 4;
+    _Float16* x16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * C * 4;
+    _Float16* xo16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * C * 4;
+    _Float16* q16 = reinterpret_cast<_Float16*>(sc);
+    HIP_OK(hipMemcpyAsync(d_stream, hs.data(), hs.size() * 2, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(d_c, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));                      // (the host vectors go out of scope)
+    if (inner) HIP_OK(launch_to_p16(d_att, inner, nullptr, M, inner, inner, att16, 2 * inner, 2048.0f, s));
+    HIP_OK(launch_to_p16(d_x, C, nullptr, M, C, C, x16, 2 * C, 2048.0f, s));
+    ChainArgs a;
+    a.M = M; a.C = C; a.inner = inner; a.att16 = att16; a.ld_att = 2 * inner; a.x16 = x16; a.ld_x = 2 * C;
+    a.wstream = d_stream; a.stream_frags = frags;
+    a.wsum1 = d_c; a.b1 = d_c + 4 * C; a.p0 = d_c + 8 * C; a.p1 = d_c + 12 * C; a.b_out = d_c + 16 * C; a.b2 = d_c + 17 * C;
+    if (n_qkv) { a.wsum_qkv = d_c + 18 * C; a.b_qkv = d_c + 18 * C + n_qkv; a.n_qkv = n_qkv; a.qkv16 = q16; a.ld_qkv = 2 * n_qkv; }
+    a.x_out = xo16; a.ld_out = 2 * C; a.x_out_mask = d_out_mask;
+    a.qb = qb; a.ch = ch;
+    HIP_OK(launch_tblock_chain(a, s));
+    HIP_OK(launch_from_p16(xo16, 2 * C, M, C, 2048.0f, d_x_out, C, s));
+    if (n_qkv && d_qkv_out) HIP_OK(launch_from_p16(q16, 2 * n_qkv, M, n_qkv, 1.0f, d_qkv_out, n_qkv, s));
     return 0;
 }
 

@@ -1,0 +1,515 @@
+// Transformer-block chain for gfx950: out-projection + residual -> LayerNorm -> FeedForward (Linear, SnakeBeta, Linear) + residual
+// -> LayerNorm -> the NEXT block's q|k|v projection, as ONE launch (kernels.h ChainArgs).
+//
+// Replaces, per BasicTransformerBlock of the reference decoder (transformer.py:261 to_out + residual, :278-301 norm3 / ff /
+// residual, :249-258 norm1 + to_q/k/v of the following block; FeedForward and SnakeBeta transformer.py:104-120,61-77), the four
+// launches gemm_p16 (out-projection), gemm_p16 (FF1 + SnakeBeta), gemm_p16 (FF2) and gemm_p16 (q|k|v) of the unfused path.
+//
+// Why this shape.  Every k-step of a 2-D tiled GEMM fetches an activation tile AND a weight tile through the CU's vector
+// memory path (~40 B/clk/CU in practice), each launch pays ~3 us until its first tile has landed and ~2.5 us of epilogue, and
+// every activation makes a round trip through HBM as a 4-byte image.  Behind the attention the block is
+// row-local, so a workgroup can own QB rows for the whole chain:
+//   * the residual-stream tile x [QB x C] lives in LDS as a P16 image (row = 128-byte lines of 32 heads | 32 residuals per
+//     32-channel group, XOR-swizzled like gemm_p16.hip's stages) and is the stationary MFMA operand of FF1 and q|k|v;
+//   * the hidden layer exists only as one [QB x CH] chunk in LDS: FF1 of a chunk, SnakeBeta, split, then straight into FF2's
+//     accumulators (QB x C, in registers for the whole FeedForward);
+//   * the weights never touch LDS.  Each wave owns C/8 output channels (CH/8 hidden channels in FF1) and reads "its" panel rows as
+//     a fragment stream: 1 KiB fragments (16 rows x 32 k of one fp16 plane, lane-major) in consumption order, one
+//     global_load_dwordx4 per lane each, through a register ring of R fragments (~12 KiB per wave in flight: what a ~2k-cycle
+//     L2 round trip needs at the CU's ingest rate).  Plain loads only: the compiler's own vmcnt bookkeeping holds, no LDS-DMA,
+//     no hand-counted waits (round-2 advisor finding on gemm_p16.hip's ring);
+//   * products are computed TRANSPOSED, D^T[channel][row] = W . X^T (A = weight fragment, B = activation fragment): a lane then
+//     holds 4 consecutive channels of one row, so every LDS / global store of an epilogue is 8 bytes of one image line;
+//   * LayerNorm statistics are taken from the LDS tile (one wave per row, two passes), applied after the product as
+//     rstd (x.W'^T - mean rowsum(W')) + b' exactly as gemm_p16.hip does.
+// Arithmetic = gemm_p16.hip MODE 0: x = h + l / 2^11, products h.h + (h.l + l.h) / 2^11, fp32 accumulation.
+#include "kernels.h"
+#include "device_utils.h"
+#include <cstring>
+#include <cmath>
+
+namespace mtts {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+
+constexpr int CHAIN_NW = CHAIN_WAVES;          // waves per workgroup
+
+template <int C, int QB, int CH>
+struct ChainCfg {
+    static constexpr int NT = C / (16 * CHAIN_NW);       // 16-channel tiles of the C-wide outputs per wave
+    static constexpr int NT1 = CH / (16 * CHAIN_NW);     // 16-channel tiles of a hidden chunk per wave
+    static constexpr int MT = QB / 16;                   // 16-row tiles
+    static constexpr int KG = C / 32, KG2 = CH / 32;     // k-steps over the stream width / over a hidden chunk
+    static constexpr int NCH = 4 * C / CH;               // hidden chunks
+    static constexpr int R = C == 384 ? 12 : 8;          // register ring (fragments)
+    static constexpr int XT_BYTES = QB * C * 4, HT_BYTES = QB * CH * 4;
+    static constexpr int CT_FLOATS = 18 * C;            // column constants kept in LDS: wsum1 | b1 | p0 | p1/2 (4C each) | b_out | b2 (C each)
+    static constexpr int LDS_BYTES = XT_BYTES + HT_BYTES + 2 * QB * 4 + CT_FLOATS * 4;
+    static_assert(C % 128 == 0 && CH % 128 == 0 && QB % 16 == 0 && QB <= 64, "shape");
+    static_assert(R % (2 * NT) == 0 && R % (2 * NT1) == 0, "a ring period is a whole number of steps");
+    static_assert((KG * 2 * NT1 + KG2 * 2 * NT) % R == 0 && (KG * 2 * NT) % R == 0, "phases start on ring slot 0");
+    static_assert(((R / (2 * NT)) & 1) == 0, "out-projection: even number of steps per ring period");
+};
+
+// ------------------------------------------------------------------------------------------------ host: fragment streams
+// Per wave: [out-projection: inner/32 steps x NT tiles][per hidden chunk: C/32 steps x NT1 tiles (FF1), CH/32 steps x NT tiles
+// (FF2)][q|k|v: passes x C/32 steps x NT tiles][R padding fragments]; a tile = fragment of the head plane, then of the residual plane.
+static int chain_ring(int C) { return C == 384 ? 12 : 8; }
+static int chain_qkv_passes(int C, int n_qkv) {
+    const int per_pass = CHAIN_NW * (C / 128);          // 16-channel tiles per pass
+    return n_qkv > 0 ? ((n_qkv / 16) + per_pass - 1) / per_pass : 0;
+}
+long chain_stream_frags(int C, int inner, int ch, int n_qkv) {
+    const int NT = C / 128, NT1 = ch / 128;
+    long f = (long)(inner / 32) * 2 * NT;
+    f += (long)(4 * C / ch) * ((C / 32) * 2 * NT1 + (ch / 32) * 2 * NT);
+    f += (long)chain_qkv_passes(C, n_qkv) * (C / 32) * 2 * NT;
+    return f + chain_ring(C);
+}
+bool chain_supported(int C, int inner, int n_qkv) {
+    if (C != 128 && C != 256 && C != 384) return false;
+    if (inner < 0 || (inner % 32) || inner > C) return false;
+    const int NT = C / 128, R = chain_ring(C);
+    if (inner && ((inner / 32) * 2 * NT) % R) return false;          // the out-projection ends on ring slot 0
+    if (n_qkv && ((n_qkv % 32) || !inner)) return false;
+    return true;
+}
+static void put_frag(uint16_t* dst, const float* w, int ldw, int n0, int n_valid, int k0, bool* sat) {
+    // dst: [plane][64 lanes][8]; lane (r = lane & 15, q = lane >> 4) holds row n0 + r, k = k0 + 8 q .. + 7
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + (lane & 15), k = k0 + 8 * (lane >> 4) + j;
+            const float x = n < n_valid ? w[(size_t)n * ldw + k] : 0.f;
+            if (std::fabs(x) > 65504.f && sat) *sat = true;
+            const float xc = x < -65504.f ? -65504.f : (x > 65504.f ? 65504.f : x);
+            const _Float16 h = (_Float16)xc;
+            float r = (x - (float)h) * F16_RES_SCALE;
+            r = r < -65504.f ? -65504.f : (r > 65504.f ? 65504.f : r);
+            const _Float16 l = (_Float16)r;
+            std::memcpy(&dst[lane * 8 + j], &h, 2);
+            std::memcpy(&dst[512 + lane * 8 + j], &l, 2);
+        }
+}
+void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, const float* w1, const float* w2, const float* w_qkv,
+                       uint16_t* dst, bool* saturates) {
+    const int NT = C / 128, NT1 = ch / 128, KG = C / 32, KG2 = ch / 32, NCH = 4 * C / ch;
+    const long per_wave = chain_stream_frags(C, inner, ch, n_qkv);
+    const int passes = chain_qkv_passes(C, n_qkv);
+    for (int w = 0; w < CHAIN_NW; ++w) {
+        uint16_t* o = dst + (size_t)w * per_wave * 512;
+        if (inner && w_out)
+            for (int s = 0; s < inner / 32; ++s)
+                for (int t = 0; t < NT; ++t, o += 1024) put_frag(o, w_out, inner, 16 * (w * NT + t), C, 32 * s, saturates);
+        for (int j = 0; j < NCH; ++j) {
+            for (int s = 0; s < KG; ++s)
+                for (int t = 0; t < NT1; ++t, o += 1024) put_frag(o, w1, C, j * ch + 16 * (w * NT1 + t), 4 * C, 32 * s, saturates);
+            for (int s = 0; s < KG2; ++s)
+                for (int t = 0; t < NT; ++t, o += 1024) put_frag(o, w2, 4 * C, 16 * (w * NT + t), C, j * ch + 32 * s, saturates);
+        }
+        for (int ps = 0; ps < passes; ++ps)
+            for (int s = 0; s < KG; ++s)
+                for (int t = 0; t < NT; ++t, o += 1024)
+                    put_frag(o, w_qkv, C, 16 * (ps * CHAIN_NW * NT + w * NT + t), n_qkv, 32 * s, saturates);
+        std::memset(o, 0, (size_t)chain_ring(C) * 512 * sizeof(uint16_t));      // (a fragment = 512 halves)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ device
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// Vector-memory loads whose PLACE in the instruction stream matters (the weight ring, the attention rows, the column constants)
+// are inline asm: hipcc otherwise sinks a load towards its use when registers are tight, which turns the ring into one exposed
+// L2 round trip per k-step (seen in the first build of this kernel: s_waitcnt vmcnt(0) in front of every MFMA group).  The
+// compiler does not count asm loads, so their waits are written here, by the rule
+//     a load is complete once at most N vector-memory operations YOUNGER than it are outstanding  (they retire in order),
+// with N = the number of younger loads ISSUED BY THIS FILE's asm.  Anything else in the queue (the compiler's own loads and
+// stores) only makes the true count larger, i.e. the wait stricter than needed -- never too weak.  The registers a wait covers
+// are passed through an empty asm right behind it (CH_TIE): their consumers then depend on the wait and cannot be scheduled
+// above it (the MFMA-hoisting hazard of cdna_hip_programming.md rule 18).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+#define CH_LOAD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase))
+#define CH_LOAD2(d0, d1, voff, sbase) \
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" : "=&v"(d0), "=&v"(d1) : "v"(voff), "s"(sbase))
+#define CH_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n))
+#define CH_TIE(x) asm volatile("" : "+v"(x))
+
+// the fp16 split of 4 consecutive channels -> packed head / residual words (v_cvt_pk_f16_f32; the residual of the clamped value)
+__device__ __forceinline__ void split4(const f32x4 v, float lscale, u32x2& hw, u32x2& lw, float& rmax) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float x0 = v[2 * e], x1 = v[2 * e + 1];
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rmax) : "v"(x0), "v"(x1));
+        const float c0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+        const f16x2 hp = {(_Float16)c0, (_Float16)c1};
+        const f16x2 lp = {(_Float16)((c0 - (float)hp[0]) * lscale), (_Float16)((c1 - (float)hp[1]) * lscale)};
+        hw[e] = __builtin_bit_cast(unsigned int, hp);
+        lw[e] = __builtin_bit_cast(unsigned int, lp);
+    }
+}
+
+template <int C, int QB, int CH>
+__global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const ChainArgs p) {
+    using K = ChainCfg<C, QB, CH>;
+    constexpr int NT = K::NT, NT1 = K::NT1, MT = K::MT, KG = K::KG, KG2 = K::KG2, R = K::R;
+    constexpr int FW = 2 * NT, F1S = 2 * NT1;           // fragments per k-step of a C-wide product / of FF1
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // ONE array: x tile | hidden chunk / attention stages | row statistics
+    char* const XT = lds;
+    char* const HT = lds + K::XT_BYTES;
+    float* const srow = reinterpret_cast<float*>(lds + K::XT_BYTES + K::HT_BYTES);
+    float* const CT = srow + 2 * QB;                      // column constants (see ChainCfg::CT_FLOATS)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, swz = (c >> 1) & 7;     // fragment coordinates: row / channel c, k block q
+    const int M = p.M, m0 = blockIdx.x * QB;
+    const bool has_out = p.inner > 0, has_qkv = p.b_qkv != nullptr;
+    const unsigned int lane16 = lane * 16, q16 = q * 16;            // per-lane byte offsets of the asm loads
+
+    // ---- the wave's weight stream through a register ring: fragment f of the current position sits in ring[f % R].
+    // wpos: (uniform) address of the fragment that is the current position.
+    const char* wpos = reinterpret_cast<const char*>(p.wstream) + (size_t)wave * (size_t)p.stream_frags * 1024;
+    u32x4 ring[R];
+#pragma unroll
+    for (int i = 0; i < R; i += 2) CH_LOAD2(ring[i], ring[i + 1], lane16, wpos + i * 1024);
+    // refill the two slots of tile t of a step whose first fragment is `frag` (position-relative) with the fragments R further on
+    auto refill = [&](int slot, int frag) __attribute__((always_inline)) {
+        CH_LOAD2(ring[slot % R], ring[(slot + 1) % R], lane16, wpos + (frag + R) * 1024);
+    };
+
+    // ---- staging coordinates (8 lanes per 128-byte line): thread -> row tid >> 3, 16-byte chunk tid & 7
+    const int st_row = tid >> 3, st_chunk = tid & 7;
+    const bool st_on = st_row < QB;
+    const size_t st_grow = (size_t)min(m0 + st_row, M - 1);
+    const int st_lds = st_row * 128 + ((st_chunk ^ ((st_row >> 1) & 7)) * 16);
+    const unsigned int att_off = (unsigned int)((st_grow * p.ld_att + st_chunk * 8) * 2);
+    u32x4 areg[2];
+    if (has_out) {
+        CH_LOAD(areg[0], att_off, reinterpret_cast<const char*>(p.att16));
+        CH_LOAD(areg[1], att_off, reinterpret_cast<const char*>(p.att16) + (p.inner > 32 ? 128 : 0));
+    }
+    // column constants -> LDS (plain loads, L2-resident): they are read per hidden chunk / per phase end, and keeping them out
+    // of registers and out of the vector-memory queue keeps the k-loops free of spills and of foreign waits
+    for (int idx = tid * 4; idx < K::CT_FLOATS; idx += 4 * 64 * CHAIN_NW) {
+        const int seg = idx < 16 * C ? idx / (4 * C) : 4 + (idx - 16 * C) / C;
+        const int o = idx < 16 * C ? idx - seg * 4 * C : idx - 16 * C - (seg - 4) * C;
+        const float* src = seg == 0 ? p.wsum1 : seg == 1 ? p.b1 : seg == 2 ? p.p0 : seg == 3 ? p.p1 : seg == 4 ? p.b_out : p.b2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (src) v = *reinterpret_cast<const f32x4*>(src + o);
+        if (seg == 3) v *= 0.5f;
+        *reinterpret_cast<f32x4*>(CT + idx) = v;
+    }
+    {   // residual stream tile -> XT (plain loads: the compiler's waits for them also cover every asm load above)
+        const _Float16* src = p.x16 + st_grow * p.ld_x + st_chunk * 8;
+#pragma unroll
+        for (int g0 = 0; g0 < KG; g0 += 4) {
+            f16x8 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f16x8*>(src + (g0 + j) * 64);
+            if (st_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8*>(XT + (g0 + j) * (QB * 128) + st_lds) = v[j];
+            }
+        }
+    }
+    CH_WAIT(0);
+#pragma unroll
+    for (int i = 0; i < R; ++i) CH_TIE(ring[i]);
+    if (has_out) { CH_TIE(areg[0]); CH_TIE(areg[1]); }
+
+    // activation fragment (B operand): rows 16 i + c of k-group kg of an image at `base`
+    auto bfrag = [&](const char* base, int kg, int i, int plane) -> f16x8 {
+        return *reinterpret_cast<const f16x8*>(base + kg * (QB * 128) + (16 * i + c) * 128 + (((plane * 4 + q) ^ swz) * 16));
+    };
+    // position of this lane's 4 consecutive channels ch..ch+3 of row 16 i + c inside an image: head word pair; the residual pair
+    // sits at the same place of chunk + 4
+    auto img_off = [&](int ch, int i, int plane) -> int {
+        const int off = ch & 31;
+        return (ch >> 5) * (QB * 128) + (16 * i + c) * 128 + ((((plane * 4) + (off >> 3)) ^ swz) * 16) + (off & 7) * 2;
+    };
+
+    f32x4 acc[NT][MT], accx[NT][MT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[t][i] = acc[t][i]; }
+    };
+    // one k-step of a C-wide product: wait for its NT weight tiles (ring slots fb ..), multiply with the activation fragments of
+    // k-group kg of `base`, then request the fragments R further on into the same slots.  The wait, by what else this file has
+    // requested since (mode): 0 nothing -- the R - FW younger fragments of the ring; 1 the out-projection's attention rows (see
+    // phase 0: FW + 1).
+    // (fb, frag, mode: constants once the caller's loop is unrolled.)
+    auto step_wide = [&](int fb, const char* base, int kg, int frag, int mode) __attribute__((always_inline)) {
+        if (mode == 0) CH_WAIT(R - FW);
+        else CH_WAIT(FW + 1);
+#pragma unroll
+        for (int f = 0; f < FW; ++f) CH_TIE(ring[(fb + f) % R]);
+        // row tiles outermost: two activation fragments live at a time, each accumulator touched again only NT MFMAs later
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f16x8 bh = bfrag(base, kg, i, 0), bl = bfrag(base, kg, i, 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) accx[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t) % R]), bl, accx[t][i]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) accx[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t + 1) % R]), bh, accx[t][i]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t) % R]), bh, acc[t][i]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) refill(fb + 2 * t, frag + 2 * t);
+    };
+    float rmax = 0.f;
+    // acc (+ bias + the residual rows in XT) -> XT, in place: this lane's channels 16 (wave NT + t) + 4 q .. + 3 of rows 16 i + c
+    auto rows_to_xt = [&](const float* bias) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ch = 16 * (wave * NT + t) + 4 * q;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                char* ph = XT + img_off(ch, i, 0);
+                char* pl = XT + img_off(ch, i, 1);
+                const f16x4 rh = *reinterpret_cast<const f16x4*>(ph), rl = *reinterpret_cast<const f16x4*>(pl);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = (acc[t][i][e] + accx[t][i][e] * (1.0f / F16_RES_SCALE) + b4[e]) + ((float)rh[e] + (float)rl[e] * (1.0f / F16_RES_SCALE));
+                u32x2 hw, lw;
+                split4(v, F16_RES_SCALE, hw, lw, rmax);
+                *reinterpret_cast<u32x2*>(ph) = hw;
+                *reinterpret_cast<u32x2*>(pl) = lw;
+            }
+        }
+    };
+    // LayerNorm moments of the rows in XT: one wave per row, two passes over the row in registers -> srow = [mean x QB | rstd x QB]
+    auto ln_stats = [&]() {
+        constexpr int RPW = QB / CHAIN_NW;
+        const bool on = lane < C / 8;                     // lane -> k-group lane >> 2, 8-channel chunk lane & 3
+        const int lk = on ? lane : 0;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = wave * RPW + rr, rs = (row >> 1) & 7;
+            const char* b = XT + (lk >> 2) * (QB * 128) + row * 128;
+            const f16x8 h = *reinterpret_cast<const f16x8*>(b + (((lk & 3) ^ rs) * 16));
+            const f16x8 l = *reinterpret_cast<const f16x8*>(b + (((4 + (lk & 3)) ^ rs) * 16));
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = on ? (float)h[e] + (float)l[e] * (1.0f / F16_RES_SCALE) : 0.f;
+            float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            s = allreduce16(s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / C);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = on ? x[e] - mean : 0.f; m2 += d * d; }
+            m2 = allreduce16(m2);
+            m2 += __shfl_xor(m2, 16);
+            m2 += __shfl_xor(m2, 32);
+            if (lane == 0) {
+                srow[row] = mean;
+                srow[QB + row] = 1.0f / sqrtf(m2 * (1.0f / C) + p.eps);
+            }
+        }
+    };
+
+    // ================================================================ phase 0: out-projection + residual (reference transformer.py:261)
+    if (has_out) {
+        constexpr int PER0 = R / FW;                     // k-steps per ring period (even)
+        constexpr int NS = KG2;                          // attention k-step stages in HT
+        const int nk0 = p.inner >> 5;
+        if (st_on) *reinterpret_cast<u32x4*>(HT + st_lds) = areg[0];
+        zero_acc();
+        __syncthreads();
+        for (int s0 = 0; s0 < nk0; s0 += PER0) {
+#pragma unroll
+            for (int u = 0; u < PER0; ++u) {
+                const int s = s0 + u;
+                // rows of step s+2 into the register that held step s (in LDS since the previous step).  Queue, oldest first:
+                // ... ATT(s+1) | refills of step s-1 (FW) | ATT(s+2): step s's weights are older than ATT(s+1), so one wait
+                // for ATT(s+1) -- FW + 1 younger loads -- covers both.
+                CH_LOAD(areg[u & 1], att_off, reinterpret_cast<const char*>(p.att16) + min(s + 2, nk0 - 1) * 128);
+                const char* stage = HT + (s % NS) * (QB * 128);
+                step_wide((u * FW) % R, stage, 0, u * FW, 1);        // (a stage holds one k-group)
+                CH_TIE(areg[(u + 1) & 1]);
+                if (st_on && s + 1 < nk0) *reinterpret_cast<u32x4*>(HT + ((s + 1) % NS) * (QB * 128) + st_lds) = areg[(u + 1) & 1];
+                __syncthreads();
+            }
+            wpos += R * 1024;
+        }
+        rows_to_xt(CT + 16 * C);
+        __syncthreads();
+    } else {
+        __syncthreads();                                  // the x tile is in LDS
+    }
+    ln_stats();
+    __syncthreads();
+
+    // ================================================================ phase 1: FeedForward (reference transformer.py:278-301,104-120)
+    zero_acc();
+    {
+        constexpr int F1 = KG * F1S;                      // fragments of a chunk's FF1 part
+        for (int j = 0; j < K::NCH; ++j) {
+            f32x4 a1[NT1][MT], a1x[NT1][MT];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { a1[t][i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1x[t][i] = a1[t][i]; }
+            // ---- FF1: hidden chunk^T = W1'[chunk] . x^T
+#pragma unroll
+            for (int s = 0; s < KG; ++s) {
+                const int fb = (s * F1S) % R;
+                CH_WAIT(R - F1S);
+#pragma unroll
+                for (int f = 0; f < F1S; ++f) CH_TIE(ring[(fb + f) % R]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const f16x8 bh = bfrag(XT, s, i, 0), bl = bfrag(XT, s, i, 1);
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) a1x[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t) % R]), bl, a1x[t][i]);
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) a1[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t) % R]), bh, a1[t][i]);
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) a1x[t][i] = mfma16(__builtin_bit_cast(f16x8, ring[(fb + 2 * t + 1) % R]), bh, a1x[t][i]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) refill(fb + 2 * t, s * F1S + 2 * t);
+            }
+            // ---- LayerNorm after the product, SnakeBeta, split -> hidden chunk image in HT
+            float nmr[MT], rstd[MT];                      // this lane's rows: -mean rstd, rstd
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { rstd[i] = srow[QB + 16 * i + c]; nmr[i] = -(srow[16 * i + c] * rstd[i]); }
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+                const int hl = 16 * (wave * NT1 + t) + 4 * q;          // channel inside the chunk
+                const float* cc = CT + j * CH + hl;
+                const f32x4 cw = *reinterpret_cast<const f32x4*>(cc), cb = *reinterpret_cast<const f32x4*>(cc + 4 * C),
+                            cs0 = *reinterpret_cast<const f32x4*>(cc + 8 * C), cs1h = *reinterpret_cast<const f32x4*>(cc + 12 * C);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = a1[t][i][e] + a1x[t][i][e] * (1.0f / F16_RES_SCALE);
+                        const float z = __builtin_fmaf(y, rstd[i], __builtin_fmaf(nmr[i], cw[e], cb[e]));
+                        v[e] = snake_hw(z, cs0[e], cs1h[e]);
+                    }
+                    u32x2 hw, lw;
+                    split4(v, F16_RES_SCALE, hw, lw, rmax);
+                    *reinterpret_cast<u32x2*>(HT + img_off(hl, i, 0)) = hw;
+                    *reinterpret_cast<u32x2*>(HT + img_off(hl, i, 1)) = lw;
+                }
+            }
+            __syncthreads();
+            // ---- FF2: out^T += W2[:, chunk] . hidden chunk^T
+#pragma unroll
+            for (int s = 0; s < KG2; ++s) step_wide((F1 + s * FW) % R, HT, s, F1 + s * FW, 0);
+            wpos += (F1 + KG2 * FW) * 1024;
+            __syncthreads();                              // the hidden chunk may be overwritten
+        }
+    }
+    rows_to_xt(CT + 17 * C);
+    __syncthreads();
+
+    // ---- the block's output rows: LDS image -> global image, whole 16-byte chunks, coalesced
+    {
+        constexpr int CPR = C / 4;                        // 16-byte chunks per row
+        for (int idx = tid; idx < QB * CPR; idx += 64 * CHAIN_NW) {
+            const int row = idx / CPR, cc = idx - row * CPR;
+            if (m0 + row < M) {
+                f16x8 v = *reinterpret_cast<const f16x8*>(XT + (cc >> 3) * (QB * 128) + row * 128 + (((cc & 7) ^ ((row >> 1) & 7)) * 16));
+                if (p.x_out_mask && p.x_out_mask[m0 + row] == 0.f) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<f16x8*>(p.x_out + (size_t)(m0 + row) * p.ld_out + cc * 8) = v;
+            }
+        }
+    }
+
+    // ================================================================ phase 2: the next block's q|k|v (reference transformer.py:249-258)
+    if (has_qkv) {
+        ln_stats();
+        float* const QC = reinterpret_cast<float*>(HT);   // the hidden-chunk area is free: panel row sums | bias of the q|k|v columns
+        for (int idx = tid * 4; idx < 2 * p.n_qkv; idx += 4 * 64 * CHAIN_NW)
+            *reinterpret_cast<f32x4*>(QC + idx) = *reinterpret_cast<const f32x4*>(idx < p.n_qkv ? p.wsum_qkv + idx : p.b_qkv + (idx - p.n_qkv));
+        __syncthreads();
+        const int ntiles = p.n_qkv >> 4;
+        const int passes = (ntiles + CHAIN_NW * NT - 1) / (CHAIN_NW * NT);
+        for (int ps = 0; ps < passes; ++ps) {
+            zero_acc();
+#pragma unroll
+            for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, 0);
+            wpos += KG * FW * 1024;
+            float nmr[MT], rstd[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { rstd[i] = srow[QB + 16 * i + c]; nmr[i] = -(srow[16 * i + c] * rstd[i]); }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tile = ps * CHAIN_NW * NT + wave * NT + t;
+                if (tile < ntiles) {
+                    const int col = 16 * tile + 4 * q;
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(QC + col), b4 = *reinterpret_cast<const f32x4*>(QC + p.n_qkv + col);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = m0 + 16 * i + c;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = acc[t][i][e] + accx[t][i][e] * (1.0f / F16_RES_SCALE);
+                            v[e] = __builtin_fmaf(y, rstd[i], __builtin_fmaf(nmr[i], w4[e], b4[e]));
+                        }
+                        u32x2 hw, lw;
+                        split4(v, 1.0f, hw, lw, rmax);      // unscaled residuals: the attention kernel's operands
+                        if (row < M) {
+                            _Float16* dst = p.qkv16 + (size_t)row * p.ld_qkv + (col >> 5) * 64 + (col & 31);
+                            *reinterpret_cast<u32x2*>(dst) = hw;
+                            *reinterpret_cast<u32x2*>(dst + 32) = lw;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    raise_range_flag(p.range_flag, rmax > 65504.f);
+}
+
+template <int C, int QB, int CH>
+static hipError_t launch_chain_shape(const ChainArgs& a, hipStream_t s) {
+    using K = ChainCfg<C, QB, CH>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+    static bool configured = false;
+    auto kern = tblock_chain_kernel<C, QB, CH>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + QB - 1) / QB), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tblock_chain(const ChainArgs& a, hipStream_t s) {
+    if (a.M <= 0 || !a.x16 || !a.wstream || !a.x_out || !a.b1 || !a.wsum1 || !a.p0 || !a.p1 || !a.b2) return hipErrorInvalidValue;
+    if (!chain_supported(a.C, a.inner, a.n_qkv)) return hipErrorInvalidValue;
+    if (a.inner && (!a.att16 || !a.b_out || a.ld_att < 2 * a.inner || (a.ld_att & 7))) return hipErrorInvalidValue;
+    if (a.b_qkv && (!a.wsum_qkv || !a.qkv16 || a.n_qkv <= 0 || a.ld_qkv < 2 * a.n_qkv || (a.ld_qkv & 3))) return hipErrorInvalidValue;
+    if (a.ld_x < 2 * a.C || (a.ld_x & 7) || a.ld_out < 2 * a.C || (a.ld_out & 7)) return hipErrorInvalidValue;
+    if (a.stream_frags != chain_stream_frags(a.C, a.inner, a.ch, a.b_qkv ? a.n_qkv : 0)) return hipErrorInvalidValue;
+    if (a.C == 384) {
+        if (a.ch == 128 && a.qb == 64) return launch_chain_shape<384, 64, 128>(a, s);
+        if (a.ch == 128 && a.qb == 32) return launch_chain_shape<384, 32, 128>(a, s);
+        if (a.ch == 256 && a.qb == 48) return launch_chain_shape<384, 48, 256>(a, s);
+        if (a.ch == 256 && a.qb == 32) return launch_chain_shape<384, 32, 256>(a, s);
+    } else if (a.C == 256) {
+        if (a.ch == 128 && a.qb == 64) return launch_chain_shape<256, 64, 128>(a, s);
+        if (a.ch == 128 && a.qb == 32) return launch_chain_shape<256, 32, 128>(a, s);
+    } else if (a.C == 128) {
+        if (a.ch == 128 && a.qb == 64) return launch_chain_shape<128, 64, 128>(a, s);
+        if (a.ch == 128 && a.qb == 32) return launch_chain_shape<128, 32, 128>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mtts

@@ -86,3 +86,63 @@ def test_hparams_roundtrip_from_reference_kwargs(hparams):
         kw = hp.as_reference_kwargs()
         kw["decoder"]["down_block_type"] = "conformer"
         hparams.from_reference_kwargs(**kw)
+
+
+@pytest.mark.parametrize("C,inner,ch,n_qkv", [(384, 384, 128, 1152), (384, 384, 256, 1152), (256, 192, 128, 576), (128, 128, 128, 0)])
+def test_chain_fragment_stream_layout(lib, C, inner, ch, n_qkv):
+    """Host packing of the transformer-block chain's weight stream (csrc/tblock_chain.hip), checked WITHOUT a GPU by walking
+    the stream exactly as the kernel does -- per wave, per phase, per k-step, per tile: head fragment then residual fragment,
+    lane (r, q) = panel row n0 + r, columns k0 + 8 q .. + 7 -- and rebuilding every panel from it (h + l / 2^11 == w to 22 bits)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    w_out = rng.standard_normal((C, inner)).astype(np.float32)
+    w1 = rng.standard_normal((4 * C, C)).astype(np.float32)
+    w2 = rng.standard_normal((C, 4 * C)).astype(np.float32)
+    w_qkv = rng.standard_normal((n_qkv, C)).astype(np.float32) if n_qkv else None
+    frags = lib.mtts_chain_stream_frags(C, inner, ch, n_qkv)
+    assert frags > 0
+    dst = np.full(frags * 8 * 512 + 64, 0x7E00, dtype=np.uint16)            # NaN canary behind the buffer
+    assert lib.mtts_chain_stream_pack(C, inner, ch, n_qkv, w_out.ctypes.data, w1.ctypes.data, w2.ctypes.data,
+                                      w_qkv.ctypes.data if n_qkv else None, dst.ctypes.data) == 0
+    assert (dst[-64:] == 0x7E00).all()                                       # nothing written past the end
+    stream = dst[:-64].view(np.float16).reshape(8, frags, 64, 8).astype(np.float64)
+    NT, NT1, KG, KG2, R = C // 128, ch // 128, C // 32, ch // 32, (12 if C == 384 else 8)
+    lane = np.arange(64)
+    r, q = lane & 15, lane >> 4
+    got = {"out": np.zeros_like(w_out, dtype=np.float64), "w1": np.zeros_like(w1, dtype=np.float64),
+           "w2": np.zeros_like(w2, dtype=np.float64), "qkv": np.zeros((n_qkv, C))}
+
+    def take(panel, wave_frags, pos, n0, k0, n_valid):
+        h, l = wave_frags[pos], wave_frags[pos + 1]
+        val = h + l / 2048.0
+        for j in range(8):
+            rows = n0 + r
+            ok = rows < n_valid
+            panel[rows[ok], (k0 + 8 * q + j)[ok]] = val[ok, j]
+        if (n0 + 15) >= n_valid:                                            # padding rows of a partly empty tile are zero
+            assert (val[(n0 + r) >= n_valid] == 0).all()
+        return pos + 2
+
+    passes = -(-(n_qkv // 16) // (8 * NT)) if n_qkv else 0
+    for w in range(8):
+        f, pos = stream[w], 0
+        for s in range(inner // 32):
+            for t in range(NT):
+                pos = take(got["out"], f, pos, 16 * (w * NT + t), 32 * s, C)
+        assert pos % R == 0                                                   # the FeedForward starts on ring slot 0
+        for j in range(4 * C // ch):
+            for s in range(KG):
+                for t in range(NT1):
+                    pos = take(got["w1"], f, pos, j * ch + 16 * (w * NT1 + t), 32 * s, 4 * C)
+            for s in range(KG2):
+                for t in range(NT):
+                    pos = take(got["w2"], f, pos, 16 * (w * NT + t), j * ch + 32 * s, C)
+            assert pos % R == 0
+        for ps in range(passes):
+            for s in range(KG):
+                for t in range(NT):
+                    pos = take(got["qkv"], f, pos, 16 * (ps * 8 * NT + w * NT + t), 32 * s, n_qkv)
+        assert pos + R == frags and (f[pos:] == 0).all()                      # the ring's run-out reads zeros
+    for name, ref in (("out", w_out), ("w1", w1), ("w2", w2), ("qkv", w_qkv)):
+        if ref is not None and ref.size:
+            assert np.abs(got[name] - ref).max() <= 2.0 ** -21 * np.abs(ref).max(), name

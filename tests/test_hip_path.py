@@ -218,6 +218,63 @@ def test_prod_fp32_operand_path_vs_golden(prod, synthetic, dev, monkeypatch):
     assert maxabs(out["mel"], ref["mel"]) < 2e-4
 
 
+@pytest.mark.parametrize("qb,ch", [("64", "128"), ("32", "128"), ("48", "256")])
+def test_prod_chain_launch_vs_golden(prod, synthetic, dev, monkeypatch, qb, ch):
+    """The transformer blocks' row-local part as ONE launch (csrc/tblock_chain.hip: out-projection, FeedForward, the next block's
+    q|k|v).  The library takes it from MTTS_CHAIN_MIN_ROWS estimator rows on (large batches); forced here on one utterance: same
+    goldens as the four-launch path, and within rounding of it; every workgroup shape."""
+    hp, sd, model = prod
+    g = np.load(GOLDEN / "prod_synth.npz")
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
+    z = synthetic.cpu_noise((1, 100, 640)).to(dev)
+    for k, v in (("MTTS_CHAIN_MIN_ROWS", "0"), ("MTTS_CHAIN_QB", qb), ("MTTS_CHAIN_CH", ch)):
+        monkeypatch.setenv(k, v)
+    fused = make_model(hp, sd, dev)
+    fused.decoder.solver = "euler"
+    out = fused.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    for k in ("MTTS_CHAIN_MIN_ROWS", "MTTS_CHAIN_QB", "MTTS_CHAIN_CH"):
+        monkeypatch.delenv(k)
+    assert maxabs(out["mel"], _t(g["mel_euler2"])) < MEL_TOL
+    mu_y = _t(g["mu_y"]).to(dev)
+    v = fused.decoder.estimator(mu_y + z, out["y_mask"], mu_y, torch.tensor(0.5))
+    assert maxabs(v, _t(g["v_t0.5"])) < 1e-4
+    out10 = fused.synthesise(x.to(dev), x_len.to(dev), 10, speaker=0, z=z)
+    assert maxabs(out10["mel"], _t(g["mel_euler10"])) < MEL_TOL
+    model.decoder.solver = "euler"
+    ref = model.synthesise(x.to(dev), x_len.to(dev), 10, speaker=0, z=z)       # one utterance: below the threshold, four launches
+    assert maxabs(out10["mel"], ref["mel"]) < 2e-4
+
+
+def test_chain_launch_ragged_batch_and_launch_count(hparams, synthetic, dev, monkeypatch):
+    """Ragged production-width batch through the chain launch against the recorded reference batch, and the launch count per
+    estimator evaluation: 12 blocks x (attention + chain) + 6 first q|k|v projections instead of 12 x 5."""
+    hp = hparams.prod_v20(n_spks=3)
+    sd = synthetic.make_state_dict(hp, seed=7)
+    monkeypatch.setenv("MTTS_CHAIN_MIN_ROWS", "0")
+    fused = make_model(hp, sd, dev)
+    fused.hip
+    monkeypatch.setenv("MTTS_CHAIN", "0")
+    plain = make_model(hp, sd, dev)
+    plain.hip
+    monkeypatch.delenv("MTTS_CHAIN")
+    monkeypatch.delenv("MTTS_CHAIN_MIN_ROWS")
+    g = np.load(GOLDEN / "prod_batch.npz")
+    x, x_len, spk = synthetic.make_inputs(hp, 3, 128, seed=1234, lengths=[128, 100, 77])
+    z = synthetic.cpu_noise((3, 100, 640)).to(dev)
+    counts = {}
+    for name, m in (("fused", fused), ("plain", plain)):
+        m.decoder.solver = "euler"
+        m.hip.prof_enable(True)
+        m.hip.prof_reset()
+        out = m.synthesise(x.to(dev), x_len.to(dev), 2, speaker=spk.to(dev), z=z)
+        torch.cuda.synchronize()
+        counts[name] = len(m.hip.prof_records())
+        m.hip.prof_enable(False)
+        assert maxabs(out["mel"], _t(g["mel"])) < MEL_TOL, name
+    # two evaluations: each saves 12 * 3 - 6 launches (the chain replaces out-projection, FF1, FF2 and, for 6 blocks, q|k|v)
+    assert counts["plain"] - counts["fused"] == 2 * 30, counts
+
+
 def test_prod_fp16_mode_is_opt_in_and_looser(prod, synthetic, dev, monkeypatch):
     """MTTS_GEMM_TERMS=1 (read when the context is created): the estimator multiplies only the fp16 head planes -- fp16 operand
     precision with fp32 accumulation, the arithmetic torch.autocast gives the reference on a GPU (reference inference.py:238).
@@ -305,6 +362,30 @@ def test_small_p16_decoders_vs_oracle(channels, n_blocks, heads, hparams, synthe
                                                              n_blocks=n_blocks, num_mid_blocks=1, num_heads=heads))
     sd = synthetic.make_state_dict(hp, seed=21)
     model = make_model(hp, sd, dev)
+    lengths = [14, 9, 3]
+    x, x_len, spk = synthetic.make_inputs(hp, 3, max(lengths), seed=8, lengths=lengths)
+    t_pad = 2 * ((5 * max(lengths) + 1) // 2)
+    z = synthetic.cpu_noise((3, hp.n_feats, t_pad)).to(dev)
+    model.decoder.solver = "midpoint"
+    out = model.synthesise(x.to(dev), x_len.to(dev), 2, speaker=spk.to(dev), z=z)
+    ref = oracle.synthesise(sd, hp, x, x_len, 2, speaker=spk, solver="midpoint", z=z.cpu())
+    assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"])
+    assert maxabs(out["mel"], ref["mel"]) < MEL_TOL
+
+
+@pytest.mark.parametrize("channels,n_blocks,heads", [((128, 128), 2, 2), ((256, 256), 2, 3), ((128, 256), 1, 2)])
+def test_small_p16_decoders_chain_launch_vs_oracle(channels, n_blocks, heads, hparams, synthetic, oracle, dev, monkeypatch):
+    """The chain launch on the narrow estimators (one / two 16-channel tiles per wave, attention narrower than the stream, a
+    q|k|v width that leaves the last pass partly empty), ragged, midpoint, against the oracle run here."""
+    import dataclasses
+    hp = hparams.tiny(n_spks=2)
+    hp = dataclasses.replace(hp, decoder=dataclasses.replace(hp.decoder, channels=channels, attention_head_dim=64,
+                                                             n_blocks=n_blocks, num_mid_blocks=1, num_heads=heads))
+    sd = synthetic.make_state_dict(hp, seed=21)
+    monkeypatch.setenv("MTTS_CHAIN_MIN_ROWS", "0")
+    model = make_model(hp, sd, dev)
+    model.hip
+    monkeypatch.delenv("MTTS_CHAIN_MIN_ROWS")
     lengths = [14, 9, 3]
     x, x_len, spk = synthetic.make_inputs(hp, 3, max(lengths), seed=8, lengths=lengths)
     t_pad = 2 * ((5 * max(lengths) + 1) // 2)
