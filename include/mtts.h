@@ -223,6 +223,11 @@ int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int in
                       const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,
                       const float* h_b2, const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb,
                       int ch, float* d_x_out, float* d_qkv_out, void* d_scratch, void* stream);
+/* the same, followed by `repeat` further launches of the kernel alone between two events: *h_ms = their mean duration */
+int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                            const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,
+                            const float* h_b2, const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask,
+                            int qb, int ch, float* d_x_out, float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms);
 
 /* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
 int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);

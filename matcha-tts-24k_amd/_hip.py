@@ -152,6 +152,8 @@ def load() -> C.CDLL:
         "mtts_chain_stream_pack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "mtts_tblock_chain_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
         "mtts_tblock_chain": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]),
+        "mtts_tblock_chain_timed": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp,
+                                          i32, C.POINTER(C.c_float)]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_channel_layernorm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
@@ -531,7 +533,7 @@ def _host(t):
     return a, a.ctypes.data
 
 
-def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv=None, out_mask=None, qb=64, ch=128):
+def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv=None, out_mask=None, qb=64, ch=128, repeat=0):
     """Row-local chain of a transformer block (csrc/tblock_chain.hip, include/mtts.h mtts_tblock_chain).  att [M, inner] (or None:
     FeedForward only), x [M, C] on the device; panels / vectors anywhere (copied to the host).  Returns (x_out, qkv or None)."""
     lib = load()
@@ -546,9 +548,13 @@ def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv
     qkv = torch.empty(M, n_qkv, dtype=torch.float32, device=x.device) if n_qkv else None
     keep = [_host(t) for t in (w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv, b_qkv)]
     hp = [k[1] for k in keep]
-    check(lib.mtts_tblock_chain(ptr(att), ptr(x), M, Cc, inner, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
-                                n_qkv, ptr(out_mask), qb, ch, ptr(x_out), ptr(qkv), scratch.data_ptr(), stream_ptr()))
+    ms = C.c_float(0.0)
+    check(lib.mtts_tblock_chain_timed(ptr(att), ptr(x), M, Cc, inner, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
+                                      n_qkv, ptr(out_mask), qb, ch, ptr(x_out), ptr(qkv), scratch.data_ptr(), stream_ptr(), repeat,
+                                      C.byref(ms)))
     torch.cuda.synchronize()
+    if repeat:
+        return x_out, qkv, ms.value
     return x_out, qkv
 
 

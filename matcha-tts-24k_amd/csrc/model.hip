@@ -667,7 +667,10 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
             } else if (last16) { a.x_out = last16; a.ld_out = 2 * C; a.x_out_mask = d.mask[lvl]; }
             else { a.x_out = d.X16; a.ld_out = 2 * C; }
             a.ch = t.chain_ch;
-            a.qb = c->chain_qb ? c->chain_qb : (a.ch == 256 ? (M >= 8192 ? 48 : 32) : (M >= 8192 ? 64 : 32));
+            // rows per workgroup: the largest the packed hidden chunk's kernel shapes have (fewer workgroups = fewer copies of the
+            // weight stream), 32 below 8192 rows so that the grid still covers the chip
+            const int qb_big = a.ch == 256 ? 48 : 64;
+            a.qb = (c->chain_qb == 32 || c->chain_qb == qb_big) ? c->chain_qb : (M >= 8192 ? qb_big : 32);
             RET_IF(run_chain(c, a, s));
             return 0;
         }
@@ -1052,7 +1055,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; c->half16 = e && atoi(e) == 16; }   // 1 / 16: fp16 modes (include/mtts.h)
     { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
     { const char* e = getenv("MTTS_CHAIN"); c->chain_on = !(e && e[0] == '0'); }
-    { const char* e = getenv("MTTS_CHAIN_CH"); c->chain_ch = (e && atoi(e) == 256) ? 256 : 128; }
+    { const char* e = getenv("MTTS_CHAIN_CH"); c->chain_ch = (e && atoi(e) == 128) ? 128 : 256; }
     { const char* e = getenv("MTTS_CHAIN_QB"); c->chain_qb = e ? atoi(e) : 0; }
     { const char* e = getenv("MTTS_CHAIN_MIN_ROWS"); if (e) c->chain_min_rows = atoi(e); }
     return c;
@@ -1582,6 +1585,13 @@ int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int in
                       const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
                       const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
                       float* d_qkv_out, void* d_scratch, void* stream) {
+    return mtts_tblock_chain_timed(d_att, d_x, M, C, inner, h_w_out, h_b_out, h_w1, h_b1, h_p0, h_p1, h_w2, h_b2, h_w_qkv, h_b_qkv, n_qkv,
+                                   d_out_mask, qb, ch, d_x_out, d_qkv_out, d_scratch, stream, 0, nullptr);
+}
+int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                            const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
+                            const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
+                            float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!h_w_qkv) n_qkv = 0;
     if (!chain_supported(C, inner, n_qkv) || !d_x || !h_w1 || !h_w2 || !d_scratch || !d_x_out) { set_error("mtts_tblock_chain: unsupported shape or null buffer"); return -1; }
@@ -1624,7 +1634,27 @@ int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int in
     if (n_qkv) { a.wsum_qkv = d_c + 18 * C; a.b_qkv = d_c + 18 * C + n_qkv; a.n_qkv = n_qkv; a.qkv16 = q16; a.ld_qkv = 2 * n_qkv; }
     a.x_out = xo16; a.ld_out = 2 * C; a.x_out_mask = d_out_mask;
     a.qb = qb; a.ch = ch;
+#ifdef MTTS_CHAIN_STAMP
+    a.kstamp = reinterpret_cast<unsigned long long*>(d_qkv_out);      // (diagnostic build: the stamps land in the q|k|v output buffer)
+#endif
     HIP_OK(launch_tblock_chain(a, s));
+#ifdef MTTS_CHAIN_STAMP
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+#endif
+    if (repeat > 0 && h_ms) {                             // measurement: `repeat` further launches between two events
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, s));
+        for (int i = 0; i < repeat; ++i) HIP_OK(launch_tblock_chain(a, s));
+        HIP_OK(hipEventRecord(e1, s));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(h_ms, e0, e1));
+        *h_ms /= (float)repeat;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     HIP_OK(launch_from_p16(xo16, 2 * C, M, C, 2048.0f, d_x_out, C, s));
     if (n_qkv && d_qkv_out) HIP_OK(launch_from_p16(q16, 2 * n_qkv, M, n_qkv, 1.0f, d_qkv_out, n_qkv, s));
     return 0;

@@ -45,7 +45,10 @@ struct ChainCfg {
     static constexpr int MT = QB / 16;                   // 16-row tiles
     static constexpr int KG = C / 32, KG2 = CH / 32;     // k-steps over the stream width / over a hidden chunk
     static constexpr int NCH = 4 * C / CH;               // hidden chunks
-    static constexpr int R = C == 384 ? 12 : 8;          // register ring (fragments)
+    // register ring (fragments): ~12 KiB per wave in flight.  (A 24-deep ring for 32-row workgroups spilled ring registers in the
+    // out-projection loop -- and a spill of an asm-loaded register stores it BEFORE its wait, i.e. garbage: tests/test_isa_guard.py
+    // checks that no loop of this kernel touches scratch.)
+    static constexpr int R = C == 384 ? 12 : 8;
     static constexpr int XT_BYTES = QB * C * 4, HT_BYTES = QB * CH * 4;
     static constexpr int CT_FLOATS = 18 * C;            // column constants kept in LDS: wsum1 | b1 | p0 | p1/2 (4C each) | b_out | b2 (C each)
     static constexpr int LDS_BYTES = XT_BYTES + HT_BYTES + 2 * QB * 4 + CT_FLOATS * 4;
@@ -58,7 +61,7 @@ struct ChainCfg {
 // ------------------------------------------------------------------------------------------------ host: fragment streams
 // Per wave: [out-projection: inner/32 steps x NT tiles][per hidden chunk: C/32 steps x NT1 tiles (FF1), CH/32 steps x NT tiles
 // (FF2)][q|k|v: passes x C/32 steps x NT tiles][R padding fragments]; a tile = fragment of the head plane, then of the residual plane.
-static int chain_ring(int C) { return C == 384 ? 12 : 8; }
+static int chain_ring(int C) { return C == 384 ? 24 : 8; }          // tail padding: the deepest ring any kernel shape uses
 static int chain_qkv_passes(int C, int n_qkv) {
     const int per_pass = CHAIN_NW * (C / 128);          // 16-channel tiles per pass
     return n_qkv > 0 ? ((n_qkv / 16) + per_pass - 1) / per_pass : 0;
@@ -74,7 +77,7 @@ bool chain_supported(int C, int inner, int n_qkv) {
     if (C != 128 && C != 256 && C != 384) return false;
     if (inner < 0 || (inner % 32) || inner > C) return false;
     const int NT = C / 128, R = chain_ring(C);
-    if (inner && ((inner / 32) * 2 * NT) % R) return false;          // the out-projection ends on ring slot 0
+    if (inner && ((inner / 32) * 2 * NT) % R) return false;          // the out-projection ends on ring slot 0 (of every ring depth)
     if (n_qkv && ((n_qkv % 32) || !inner)) return false;
     return true;
 }
@@ -119,6 +122,12 @@ void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, 
 }
 
 // ------------------------------------------------------------------------------------------------ device
+// diagnostic builds (-DMTTS_CHAIN_STAMP, tools/chain_sweep.py --stamps): s_memtime of wave 0 of workgroup 0 at the phase boundaries
+#ifdef MTTS_CHAIN_STAMP
+#define CH_STAMP(i) do { if (p.kstamp && blockIdx.x == 0 && tid == 0) p.kstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CH_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // Vector-memory loads whose PLACE in the instruction stream matters (the weight ring, the attention rows, the column constants)
@@ -167,7 +176,8 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     const int c = lane & 15, q = lane >> 4, swz = (c >> 1) & 7;     // fragment coordinates: row / channel c, k block q
     const int M = p.M, m0 = blockIdx.x * QB;
     const bool has_out = p.inner > 0, has_qkv = p.b_qkv != nullptr;
-    const unsigned int lane16 = lane * 16, q16 = q * 16;            // per-lane byte offsets of the asm loads
+    const unsigned int lane16 = lane * 16;                          // per-lane byte offset of the stream loads
+    CH_STAMP(0);
 
     // ---- the wave's weight stream through a register ring: fragment f of the current position sits in ring[f % R].
     // wpos: (uniform) address of the fragment that is the current position.
@@ -191,28 +201,35 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         CH_LOAD(areg[0], att_off, reinterpret_cast<const char*>(p.att16));
         CH_LOAD(areg[1], att_off, reinterpret_cast<const char*>(p.att16) + (p.inner > 32 ? 128 : 0));
     }
-    // column constants -> LDS (plain loads, L2-resident): they are read per hidden chunk / per phase end, and keeping them out
-    // of registers and out of the vector-memory queue keeps the k-loops free of spills and of foreign waits
-    for (int idx = tid * 4; idx < K::CT_FLOATS; idx += 4 * 64 * CHAIN_NW) {
-        const int seg = idx < 16 * C ? idx / (4 * C) : 4 + (idx - 16 * C) / C;
-        const int o = idx < 16 * C ? idx - seg * 4 * C : idx - 16 * C - (seg - 4) * C;
-        const float* src = seg == 0 ? p.wsum1 : seg == 1 ? p.b1 : seg == 2 ? p.p0 : seg == 3 ? p.p1 : seg == 4 ? p.b_out : p.b2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (src) v = *reinterpret_cast<const f32x4*>(src + o);
-        if (seg == 3) v *= 0.5f;
-        *reinterpret_cast<f32x4*>(CT + idx) = v;
-    }
-    {   // residual stream tile -> XT (plain loads: the compiler's waits for them also cover every asm load above)
+    // residual stream tile and column constants -> LDS.  Every load is requested before the first LDS write: one round trip for
+    // the whole prologue (plain loads; the compiler's waits for them also cover every asm load above).  The constants are read
+    // per hidden chunk / per phase end; keeping them out of registers and out of the vector-memory queue keeps the k-loops free
+    // of spills and of foreign waits.
+    {
         const _Float16* src = p.x16 + st_grow * p.ld_x + st_chunk * 8;
+        f16x8 xv[KG];
 #pragma unroll
-        for (int g0 = 0; g0 < KG; g0 += 4) {
-            f16x8 v[4];
+        for (int g0 = 0; g0 < KG; ++g0) xv[g0] = *reinterpret_cast<const f16x8*>(src + g0 * 64);
+        constexpr int NCT = (K::CT_FLOATS / 4 + 64 * CHAIN_NW - 1) / (64 * CHAIN_NW);      // f32x4 per thread
+        f32x4 cv[NCT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f16x8*>(src + (g0 + j) * 64);
-            if (st_on) {
+        for (int n = 0; n < NCT; ++n) {
+            const int idx = (tid + n * 64 * CHAIN_NW) * 4;
+            const int seg = idx < 16 * C ? idx / (4 * C) : 4 + (idx - 16 * C) / C;
+            const int o = idx < 16 * C ? idx - seg * 4 * C : idx - 16 * C - (seg - 4) * C;
+            const float* srcc = seg == 0 ? p.wsum1 : seg == 1 ? p.b1 : seg == 2 ? p.p0 : seg == 3 ? p.p1 : seg == 4 ? p.b_out : p.b2;
+            cv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < K::CT_FLOATS && srcc) cv[n] = *reinterpret_cast<const f32x4*>(srcc + o);
+            if (seg == 3) cv[n] *= 0.5f;
+        }
+        if (st_on) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8*>(XT + (g0 + j) * (QB * 128) + st_lds) = v[j];
-            }
+            for (int g0 = 0; g0 < KG; ++g0) *reinterpret_cast<f16x8*>(XT + g0 * (QB * 128) + st_lds) = xv[g0];
+        }
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) {
+            const int idx = (tid + n * 64 * CHAIN_NW) * 4;
+            if (idx < K::CT_FLOATS) *reinterpret_cast<f32x4*>(CT + idx) = cv[n];
         }
     }
     CH_WAIT(0);
@@ -241,11 +258,16 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     // one k-step of a C-wide product: wait for its NT weight tiles (ring slots fb ..), multiply with the activation fragments of
     // k-group kg of `base`, then request the fragments R further on into the same slots.  The wait, by what else this file has
     // requested since (mode): 0 nothing -- the R - FW younger fragments of the ring; 1 the out-projection's attention rows (see
-    // phase 0: FW + 1).
+    // phase 0: FW + 1); 2 the 2 NT MT image stores of the previous q|k|v pass's epilogue, when this workgroup issued exactly that
+    // many (`stores_exact`: all rows valid, all tiles valid) -- they are younger than fragments requested before that epilogue,
+    // and not counting them would make the first steps of a pass wait for the stores' round trip.
     // (fb, frag, mode: constants once the caller's loop is unrolled.)
+    bool stores_exact = false;
     auto step_wide = [&](int fb, const char* base, int kg, int frag, int mode) __attribute__((always_inline)) {
         if (mode == 0) CH_WAIT(R - FW);
-        else CH_WAIT(FW + 1);
+        else if (mode == 1) CH_WAIT(FW + 1);
+        else if (stores_exact) CH_WAIT(R - FW + 2 * NT * MT);
+        else CH_WAIT(R - FW);
 #pragma unroll
         for (int f = 0; f < FW; ++f) CH_TIE(ring[(fb + f) % R]);
         // row tiles outermost: two activation fragments live at a time, each accumulator touched again only NT MFMAs later
@@ -285,35 +307,35 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             }
         }
     };
-    // LayerNorm moments of the rows in XT: one wave per row, two passes over the row in registers -> srow = [mean x QB | rstd x QB]
+    // LayerNorm moments of the rows in XT -> srow = [mean x QB | rstd x QB].  A wave takes QB/8 rows, 8 lanes per row (each C/64
+    // 8-channel chunks of it), all rows at once: two passes over values held in registers, reductions over 8 lanes by DPP.
     auto ln_stats = [&]() {
-        constexpr int RPW = QB / CHAIN_NW;
-        const bool on = lane < C / 8;                     // lane -> k-group lane >> 2, 8-channel chunk lane & 3
-        const int lk = on ? lane : 0;
+        constexpr int RPW = QB / CHAIN_NW, CPL = C / 64;  // rows per wave; chunks per lane
+        const int rl = lane >> 3, part = lane & 7;
+        const bool on = rl < RPW;
+        const int row = wave * RPW + (on ? rl : 0), rs = (row >> 1) & 7;
+        float x[CPL][8];
+        float s = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int row = wave * RPW + rr, rs = (row >> 1) & 7;
-            const char* b = XT + (lk >> 2) * (QB * 128) + row * 128;
-            const f16x8 h = *reinterpret_cast<const f16x8*>(b + (((lk & 3) ^ rs) * 16));
-            const f16x8 l = *reinterpret_cast<const f16x8*>(b + (((4 + (lk & 3)) ^ rs) * 16));
-            float x[8];
+        for (int k = 0; k < CPL; ++k) {
+            const int ck = part * CPL + k;                // 8-channel chunk of the row: k-group ck >> 2, chunk ck & 3
+            const char* b = XT + (ck >> 2) * (QB * 128) + row * 128;
+            const f16x8 h = *reinterpret_cast<const f16x8*>(b + (((ck & 3) ^ rs) * 16));
+            const f16x8 l = *reinterpret_cast<const f16x8*>(b + (((4 + (ck & 3)) ^ rs) * 16));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = on ? (float)h[e] + (float)l[e] * (1.0f / F16_RES_SCALE) : 0.f;
-            float s = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-            s = allreduce16(s);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const float mean = s * (1.0f / C);
-            float m2 = 0.f;
+            for (int e = 0; e < 8; ++e) x[k][e] = (float)h[e] + (float)l[e] * (1.0f / F16_RES_SCALE);
+            s += ((x[k][0] + x[k][1]) + (x[k][2] + x[k][3])) + ((x[k][4] + x[k][5]) + (x[k][6] + x[k][7]));
+        }
+        const float mean = allreduce8(s) * (1.0f / C);
+        float m2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = on ? x[e] - mean : 0.f; m2 += d * d; }
-            m2 = allreduce16(m2);
-            m2 += __shfl_xor(m2, 16);
-            m2 += __shfl_xor(m2, 32);
-            if (lane == 0) {
-                srow[row] = mean;
-                srow[QB + row] = 1.0f / sqrtf(m2 * (1.0f / C) + p.eps);
-            }
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = x[k][e] - mean; m2 += d * d; }
+        m2 = allreduce8(m2);
+        if (on && part == 0) {
+            srow[row] = mean;
+            srow[QB + row] = 1.0f / sqrtf(m2 * (1.0f / C) + p.eps);
         }
     };
 
@@ -325,6 +347,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         if (st_on) *reinterpret_cast<u32x4*>(HT + st_lds) = areg[0];
         zero_acc();
         __syncthreads();
+        CH_STAMP(1);
         for (int s0 = 0; s0 < nk0; s0 += PER0) {
 #pragma unroll
             for (int u = 0; u < PER0; ++u) {
@@ -341,6 +364,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             }
             wpos += R * 1024;
         }
+        CH_STAMP(2);
         rows_to_xt(CT + 16 * C);
         __syncthreads();
     } else {
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     }
     ln_stats();
     __syncthreads();
+    CH_STAMP(3);
 
     // ================================================================ phase 1: FeedForward (reference transformer.py:278-301,104-120)
     zero_acc();
@@ -379,6 +404,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) refill(fb + 2 * t, s * F1S + 2 * t);
             }
+            if (j < 2) CH_STAMP(4 + 3 * j);
             // ---- LayerNorm after the product, SnakeBeta, split -> hidden chunk image in HT
             float nmr[MT], rstd[MT];                      // this lane's rows: -mean rstd, rstd
 #pragma unroll
@@ -405,13 +431,16 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
                 }
             }
             __syncthreads();
+            if (j < 2) CH_STAMP(5 + 3 * j);
             // ---- FF2: out^T += W2[:, chunk] . hidden chunk^T
 #pragma unroll
             for (int s = 0; s < KG2; ++s) step_wide((F1 + s * FW) % R, HT, s, F1 + s * FW, 0);
             wpos += (F1 + KG2 * FW) * 1024;
             __syncthreads();                              // the hidden chunk may be overwritten
+            if (j < 2) CH_STAMP(6 + 3 * j);
         }
     }
+    CH_STAMP(10);
     rows_to_xt(CT + 17 * C);
     __syncthreads();
 
@@ -428,6 +457,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         }
     }
 
+    CH_STAMP(11);
     // ================================================================ phase 2: the next block's q|k|v (reference transformer.py:249-258)
     if (has_qkv) {
         ln_stats();
@@ -437,11 +467,16 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         __syncthreads();
         const int ntiles = p.n_qkv >> 4;
         const int passes = (ntiles + CHAIN_NW * NT - 1) / (CHAIN_NW * NT);
+        static_assert(R - FW + 2 * NT * MT < 64, "vmcnt is a 6-bit counter");
+        const bool all_stores = m0 + QB <= M && ntiles % (CHAIN_NW * NT) == 0;      // (uniform) every store of an epilogue is issued
         for (int ps = 0; ps < passes; ++ps) {
             zero_acc();
+            stores_exact = all_stores && ps > 0;
+            // fragments with index < R (relative to the pass) were requested during the previous pass's k-loop, before its stores
 #pragma unroll
-            for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, 0);
+            for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, (s * FW + FW - 1 < R) ? 2 : 0);
             wpos += KG * FW * 1024;
+            CH_STAMP(13 + (ps < 2 ? ps : 2));
             float nmr[MT], rstd[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) { rstd[i] = srow[QB + 16 * i + c]; nmr[i] = -(srow[16 * i + c] * rstd[i]); }
@@ -462,7 +497,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
                         }
                         u32x2 hw, lw;
                         split4(v, 1.0f, hw, lw, rmax);      // unscaled residuals: the attention kernel's operands
-                        if (row < M) {
+                        if (all_stores || row < M) {
                             _Float16* dst = p.qkv16 + (size_t)row * p.ld_qkv + (col >> 5) * 64 + (col & 31);
                             *reinterpret_cast<u32x2*>(dst) = hw;
                             *reinterpret_cast<u32x2*>(dst + 32) = lw;
@@ -473,6 +508,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         }
     }
     raise_range_flag(p.range_flag, rmax > 65504.f);
+    CH_STAMP(12);
 }
 
 template <int C, int QB, int CH>

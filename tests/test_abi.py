@@ -106,7 +106,7 @@ def test_chain_fragment_stream_layout(lib, C, inner, ch, n_qkv):
                                       w_qkv.ctypes.data if n_qkv else None, dst.ctypes.data) == 0
     assert (dst[-64:] == 0x7E00).all()                                       # nothing written past the end
     stream = dst[:-64].view(np.float16).reshape(8, frags, 64, 8).astype(np.float64)
-    NT, NT1, KG, KG2, R = C // 128, ch // 128, C // 32, ch // 32, (12 if C == 384 else 8)
+    NT, NT1, KG, KG2, R = C // 128, ch // 128, C // 32, ch // 32, (24 if C == 384 else 8)
     lane = np.arange(64)
     r, q = lane & 15, lane >> 4
     got = {"out": np.zeros_like(w_out, dtype=np.float64), "w1": np.zeros_like(w1, dtype=np.float64),

@@ -231,7 +231,8 @@ def test_prod_chain_launch_vs_golden(prod, synthetic, dev, monkeypatch, qb, ch):
         monkeypatch.setenv(k, v)
     fused = make_model(hp, sd, dev)
     fused.decoder.solver = "euler"
-    out = fused.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z)
+    out = fused.synthesise(x.to(dev), x_len.to(dev), 2, speaker=0, z=z, debug=True)
+    assert not bool(fused.hip.range_flags().any().item())
     for k in ("MTTS_CHAIN_MIN_ROWS", "MTTS_CHAIN_QB", "MTTS_CHAIN_CH"):
         monkeypatch.delenv(k)
     assert maxabs(out["mel"], _t(g["mel_euler2"])) < MEL_TOL
@@ -264,6 +265,7 @@ def test_chain_launch_ragged_batch_and_launch_count(hparams, synthetic, dev, mon
     counts = {}
     for name, m in (("fused", fused), ("plain", plain)):
         m.decoder.solver = "euler"
+        m.decoder.graph_mode = "0"                        # (the per-launch event pass does not run under graph capture)
         m.hip.prof_enable(True)
         m.hip.prof_reset()
         out = m.synthesise(x.to(dev), x_len.to(dev), 2, speaker=spk.to(dev), z=z)
