@@ -18,6 +18,15 @@ import torch
 import torch.distributed as dist
 
 
+# At world size 1 every exchange is the identity and is skipped -- unless this is set: tests/test_hip_rccl.py runs the collectives
+# themselves (RCCL on device tensors) with the one GPU a test box has.
+FORCE_COLLECTIVES = False
+
+
+def _single(world: int) -> bool:
+    return world == 1 and not FORCE_COLLECTIVES
+
+
 def shard_slice(n: int, world: int, rank: int) -> slice:
     """Contiguous, balanced shard of n utterances (the first n % world ranks get one more)."""
     q, r = divmod(n, world)
@@ -31,7 +40,7 @@ def _host_staged() -> bool:
 
 
 def all_reduce_max_ints(vals: Sequence[int], device) -> List[int]:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or _single(dist.get_world_size()):
         return [int(v) for v in vals]
     t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device="cpu" if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -60,7 +69,7 @@ def _all_gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
 
 def all_gather_mels(mel: torch.Tensor, world: int) -> torch.Tensor:
     """Equal-shaped shards [b, n_feats, T] -> [b*world, n_feats, T] in rank order (one all_gather_into_tensor)."""
-    if world == 1:
+    if _single(world):
         return mel
     return _all_gather_rows(mel, world)
 
@@ -68,7 +77,7 @@ def all_gather_mels(mel: torch.Tensor, world: int) -> torch.Tensor:
 def all_gather_ragged(mel: torch.Tensor, lengths: torch.Tensor, n_total: int, world: int, rank: int
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Shards of possibly different batch size / frame count -> ([n_total, n_feats, T_max], lengths[n_total])."""
-    if world == 1:
+    if _single(world):
         return mel, lengths
     per = max(shard_slice(n_total, world, r).stop - shard_slice(n_total, world, r).start for r in range(world))
     # an empty shard knows neither the frame count nor n_feats: both come from the ranks that have rows

@@ -15,6 +15,12 @@ only small id arrays and expected outputs are stored):
                      midpoint/2, rk4/1 + a batched composition of the reference's own components
   prod_synth.npz     prod v20 shapes, Tx=128: logw, mu_y, 1-NFE decoder output, mel for euler/2, euler/10, midpoint/4
   prod_batch.npz     prod shapes, B=3 ragged lengths, euler/2 (reference components composed as synthesise does)
+  prod_autocast.npz  ANCHOR for the reduced-precision modes: the reference's synthesise (prod shapes, Tx=128, euler/10, same inputs as
+                     prod_synth) run under torch.autocast -- what matcha/inference.py:238 wraps it in -- on the CPU in bfloat16 and,
+                     where the CPU kernels exist, float16, with each result's error against the fp32 mel.  The seed-42 noise is
+                     pinned to the fp32 run's draw (under autocast mu is 16-bit and torch.randn_like would draw ANOTHER stream,
+                     which changes the whole mel); everything else is the reference's code as it stands.  CPU autocast's op list
+                     is not CUDA's: an anchor for "what 16-bit operands do to this network", not a bit-level target.
   randn42.npz        first values of the CPU seed-42 normal stream (detects an RNG mismatch on another box)
   dp_tiny.npz        duration_recipe=False (non-zero DurationPredictor projection, reference text_encoder.py:64-112):
                      B=3 ragged encoder outputs, the reference's own durations / lengths (inference.py:127-146 replayed)
@@ -216,6 +222,33 @@ def main():
     report["prod.decoder.1nfe"] = maxabs(v, ov)
     rec["v_t0.5"] = v.numpy()
     np.savez(HERE / "prod_synth.npz", **rec)
+
+    # ------------------------------------------------------------------ the same synthesis under autocast (reference inference.py:238)
+    model.decoder.solver = "euler"
+    ref32 = torch.from_numpy(rec["mel_euler10"])
+    arec = {}
+    real_randn_like = torch.randn_like
+
+    def pinned_randn_like(t, generator=None, **kw):      # the fp32 seed-42 draw of this shape, in the tensor's dtype
+        return torch.randn(t.shape, generator=generator, dtype=torch.float32).to(t.dtype)
+
+    for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        try:
+            torch.randn_like = pinned_randn_like
+            with torch.autocast(device_type="cpu", dtype=dt):
+                out = model.synthesise(x, x_len, n_timesteps=10, speaker=0)
+            mel = out["mel"].float()
+        except Exception as e:                       # (no CPU kernel for some op in this dtype)
+            report[f"prod.autocast.{name}"] = f"unavailable: {type(e).__name__}"
+            continue
+        finally:
+            torch.randn_like = real_randn_like
+        arec[f"mel_{name}"] = mel.numpy()
+        arec[f"err_{name}"] = np.array([maxabs(mel, ref32), float((mel - ref32).abs().mean())], dtype=np.float64)
+        report[f"prod.autocast.{name}.max"] = maxabs(mel, ref32)
+        report[f"prod.autocast.{name}.mean"] = float((mel - ref32).abs().mean())
+    arec["mel_abs_max"] = np.array(float(ref32.abs().max()))
+    np.savez(HERE / "prod_autocast.npz", **arec)
 
     # ------------------------------------------------------------------ prod shapes, ragged batch
     hp3 = hparams.prod_v20(n_spks=3)

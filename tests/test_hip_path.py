@@ -646,8 +646,36 @@ def test_config3_per_rank_shape_half_storage(prod, synthetic, dev, monkeypatch):
     ref = model.synthesise(x[:4].to(dev), x_len[:4].to(dev), 10, speaker=0, z=z[:4], debug=True)
     assert torch.equal(out["phoneme_durations"][:4], ref["phoneme_durations"])
     err = maxabs(mel[:4], ref["mel"])
-    print(f"config #3 arithmetic: mel max-abs error vs the fp32-equivalent path {err:.3e} (|mel| <= {float(ref['mel'].abs().max()):.1f})")
-    assert 1e-4 < err < 0.25
+    mean_err = float((mel[:4] - ref["mel"]).abs().mean())
+    print(f"config #3 arithmetic: mel error vs the fp32-equivalent path max {err:.3e} mean {mean_err:.3e} (|mel| <= {float(ref['mel'].abs().max()):.1f})")
+    # bounded by what the REFERENCE's own arithmetic does to its own mel under 16-bit autocast (tests/golden/prod_autocast.npz,
+    # recorded from the reference on the utterance-0 inputs: fp16 max 3.7e-2 / mean 6.7e-3), times a small factor for the
+    # other utterances of the batch -- not by a free-standing ceiling
+    anchor = np.load(GOLDEN / "prod_autocast.npz")["err_fp16"]
+    assert 1e-4 < err < 2.0 * anchor[0] and mean_err < 1.5 * anchor[1], (err, mean_err, anchor)
+
+
+def test_half_storage_mode_vs_reference_autocast_anchor(prod, synthetic, dev, monkeypatch):
+    """The 16-bit storage mode against the reference-derived anchor on the SAME inputs (prod_synth: Tx=128, euler/10, seed-42
+    noise): the reference's synthesise under torch.autocast(float16) -- what matcha/inference.py:238 runs -- deviates from its
+    fp32 mel by err_fp16 = (max, mean); the HIP mode (fp16 operands in HBM, one MFMA per MAC, fp32 accumulation, statistics and
+    ODE state) must deviate from the same fp32 golden by no more than 1.5x that, and its result must be about as far from the
+    autocast mel as that is from fp32 (two different roundings of one computation, not a different function)."""
+    hp, sd, model = prod
+    g = np.load(GOLDEN / "prod_synth.npz")
+    a = np.load(GOLDEN / "prod_autocast.npz")
+    half = _half_model(hp, sd, dev, monkeypatch)
+    x, x_len, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
+    z = synthetic.cpu_noise((1, 100, 640)).to(dev)
+    half.decoder.solver = "euler"
+    mel = half.synthesise(x.to(dev), x_len.to(dev), 10, speaker=0, z=z)["mel"].cpu()
+    gold = _t(g["mel_euler10"])
+    err_max, err_mean = maxabs(mel, gold), float((mel - gold).abs().mean())
+    ref_max, ref_mean = (float(v) for v in a["err_fp16"])
+    print(f"16-bit storage mode vs fp32 golden: max {err_max:.3e} mean {err_mean:.3e}; reference fp16 autocast: max {ref_max:.3e} mean {ref_mean:.3e}")
+    assert 1e-4 < err_max <= 1.5 * ref_max, (err_max, ref_max)
+    assert err_mean <= 1.5 * ref_mean, (err_mean, ref_mean)
+    assert maxabs(mel, _t(a["mel_fp16"])) <= 2.5 * ref_max
 
 
 # ------------------------------------------------------------------------------------------------ range guard

@@ -131,3 +131,18 @@ def test_duration_predictor_live(tag, which, hparams, synthetic, oracle):
                                      length_scale=ls, solver="euler")
         assert torch.equal(solo["durations"], _t(g["solo_dur"]))
         assert (solo["mel"] - _t(g["solo_mel"])).abs().max() < 1e-4
+
+
+def test_autocast_anchor_is_self_consistent():
+    """prod_autocast.npz (the reference's synthesise under torch.autocast on the prod_synth inputs, noise pinned to the fp32
+    draw): the recorded error figures are those of the recorded mels against the fp32 golden, 16-bit operands cost the
+    reference itself 1e-2..3e-1 on |mel| ~ 45, and bf16 (8 significand bits) costs several times fp16 (11)."""
+    g, a = np.load(GOLDEN / "prod_synth.npz"), np.load(GOLDEN / "prod_autocast.npz")
+    gold = _t(g["mel_euler10"])
+    for name in ("bf16", "fp16"):
+        mel = _t(a[f"mel_{name}"])
+        assert mel.shape == gold.shape
+        d = (mel - gold).abs()
+        assert abs(float(d.max()) - float(a[f"err_{name}"][0])) < 1e-6 and abs(float(d.mean()) - float(a[f"err_{name}"][1])) < 1e-6
+    assert 1e-2 < a["err_fp16"][0] < 1e-1 < a["err_bf16"][0] < 1.0
+    assert abs(float(gold.abs().max()) - float(a["mel_abs_max"])) < 1e-6
