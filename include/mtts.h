@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 #define MTTS_ABI_VERSION 2
+/* bumped whenever the packed weight image changes layout (invalidates mtts_export_weights caches) */
+#define MTTS_IMAGE_REVISION 3
 
 typedef struct mtts_ctx mtts_ctx;
 
@@ -71,6 +73,16 @@ void mtts_destroy(mtts_ctx* ctx);
  * "decoder.estimator.down_blocks.0.0.block1.block.0.weight".  h_data: host fp32, copied.
  * Replaces nn.Module.load_state_dict (reference inference.py:186-197). */
 int mtts_set_tensor(mtts_ctx* ctx, const char* key, const float* h_data, int64_t numel);
+
+/* Packed-image cache ("pre-packed MFMA weight layouts cached beside the converted checkpoint").
+ * mtts_weights_signature: a string naming everything the image layout depends on (ABI and image revision, architecture,
+ * arithmetic, layout switches); mtts_export_weights copies the packed image (mtts_weights_bytes) to host memory;
+ * mtts_import_weights adopts such an image in a context with the same signature whose tensors have been registered
+ * (mtts_set_tensor) -- it runs the layout pass only, not the splitting / fragment packing (~7 s at production size).
+ * `saturates`: the range-guard finding of the packing pass (mtts_weights_saturate), stored with the image. */
+int mtts_weights_signature(mtts_ctx* ctx, char* buf, int64_t n);
+int mtts_export_weights(mtts_ctx* ctx, void* h_dst, int64_t bytes, int* saturates);
+int mtts_import_weights(mtts_ctx* ctx, const void* h_src, int64_t bytes, int saturates);
 
 /* After all tensors are registered: size of the packed device image, then pack + upload it
  * (GEMM-ready [N][K] panels, conv taps unrolled along K, LayerNorm affine folded into the

@@ -128,6 +128,9 @@ def load() -> C.CDLL:
         "mtts_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
         "mtts_weights_bytes": (i64, [vp]),
         "mtts_upload_weights": (i32, [vp, vp, i64]),
+        "mtts_weights_signature": (i32, [vp, C.c_char_p, i64]),
+        "mtts_export_weights": (i32, [vp, vp, i64, C.POINTER(i32)]),
+        "mtts_import_weights": (i32, [vp, vp, i64, i32]),
         "mtts_encoder_workspace_bytes": (i64, [vp, i32, i32]),
         "mtts_text_encoder_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
         "mtts_speaker_embedding": (i32, [vp, i32, vp, i32, vp, vp]),
@@ -266,9 +269,18 @@ class HipModel:
         a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
         check(self.lib.mtts_set_tensor(self.ctx, key.encode(), a.ctypes.data, a.size))
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], device) -> None:
+    def weights_signature(self) -> str:
+        """Everything the packed image's layout depends on (mtts_weights_signature): the key of a packed-image cache."""
+        buf = C.create_string_buffer(1024)
+        if self.lib.mtts_weights_signature(self.ctx, buf, 1024) < 0:
+            check(-1)
+        return buf.value.decode()
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], device, cache_dir=None) -> None:
         """Register every tensor of a reference-format state dict (keys of SURVEY appendix A; torch.compile's
-        ``_orig_mod.`` infix is ignored), add the host-precomputed tables, pack and upload."""
+        ``_orig_mod.`` infix is ignored), add the host-precomputed tables, pack and upload.
+        ``cache_dir`` (a converted checkpoint's directory, checkpoint.py): the packed image is read from / written to a cache
+        file there, keyed by the library's layout signature and a digest of the tensors (``checkpoint.packed_cache``)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("mtts: weights must live on a HIP device; the HIP path has no CPU fallback")
@@ -287,9 +299,26 @@ class HipModel:
         self._set("aux.rope_cos", cos)
         self._set("aux.rope_sin", sin)
         self._set("aux.time_freqs", time_freqs(2 * self.hp.n_feats))
+        self.cache_hit = False
+        cache = None
+        if cache_dir is not None:
+            from . import checkpoint as ck
+            cache = ck.packed_cache(cache_dir, self.weights_signature(), sd)
+            image = cache.read()
+            if image is not None:
+                try:
+                    check(self.lib.mtts_import_weights(self.ctx, image["data"].ctypes.data, image["data"].nbytes, int(image["saturates"])))
+                    self.cache_hit = True
+                except RuntimeError:
+                    self.cache_hit = False       # (a stale or foreign file: pack from the tensors below and rewrite it)
         nbytes = self.lib.mtts_weights_bytes(self.ctx)
         if nbytes < 0:
             check(-1)
+        if cache is not None and not self.cache_hit:
+            host = np.empty(nbytes, dtype=np.uint8)
+            sat = C.c_int(0)
+            check(self.lib.mtts_export_weights(self.ctx, host.ctypes.data, nbytes, C.byref(sat)))
+            cache.write(host, bool(sat.value))
         self.weights = torch.empty(nbytes, dtype=torch.uint8, device=device)
         check(self.lib.mtts_upload_weights(self.ctx, self.weights.data_ptr(), nbytes))
         self.device = device

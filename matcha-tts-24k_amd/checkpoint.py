@@ -10,6 +10,11 @@ matcha/utils/prepare_ckpt_for_release.py).  Unpickling those needs lightning / o
                               tensors of the inference path (encoder, speaker tables, decoder estimator, mel statistics)
     <out>/hparams.json        the flattened path hyper-parameters (hparams.PathHParams) + format version
 
+    <out>/packed-<key>.bin    (written on first load on a GPU box) the library's packed weight image -- GEMM panels, fp16
+                              planes, fragment streams -- so that later loads skip the ~7 s host packing pass; <key> digests
+                              the library's layout signature (ABI / image revision, architecture, arithmetic, layout
+                              switches) and the tensors themselves, so a stale file is simply never looked up
+
 ``load_converted`` reads that directory back; ``inference.load_matcha`` accepts either form.
 """
 from __future__ import annotations
@@ -102,6 +107,52 @@ def load_converted(path) -> Tuple[H.PathHParams, Dict[str, torch.Tensor]]:
     hp = hparams_from_json(json.loads((p / HPARAMS).read_text()))
     sd = load_file(str(p / WEIGHTS), device="cpu")
     return hp, select_path_tensors(hp, sd)
+
+
+class packed_cache:
+    """The packed-image cache file of one (library signature, tensors) pair inside a converted checkpoint's directory."""
+    MAGIC = b"MTTSIMG1"
+
+    def __init__(self, directory, signature: str, sd: Dict[str, torch.Tensor]):
+        import hashlib
+        h = hashlib.sha256(signature.encode())
+        for k in sorted(sd):
+            t = sd[k].detach().to("cpu", torch.float32).contiguous()
+            h.update(k.encode())
+            h.update(str(tuple(t.shape)).encode())
+            h.update(t.numpy().tobytes())
+        self.signature = signature
+        self.path = Path(directory) / f"packed-{h.hexdigest()[:24]}.bin"
+
+    def read(self):
+        """{"data": uint8 array, "saturates": bool} or None (no file / damaged file)."""
+        import numpy as np
+        try:
+            with open(self.path, "rb") as f:
+                head = f.read(24)
+                if len(head) != 24 or head[:8] != self.MAGIC:
+                    return None
+                nbytes = int.from_bytes(head[8:16], "little")
+                sat = int.from_bytes(head[16:24], "little")
+                data = np.fromfile(f, dtype=np.uint8, count=nbytes)
+            return {"data": data, "saturates": bool(sat)} if data.size == nbytes else None
+        except OSError:
+            return None
+
+    def write(self, image, saturates: bool) -> None:
+        """Best effort (a read-only model directory is not an error); written under a temporary name, then renamed."""
+        import os
+        tmp = self.path.with_suffix(".tmp%d" % os.getpid())
+        try:
+            with open(tmp, "wb") as f:
+                f.write(self.MAGIC + int(image.nbytes).to_bytes(8, "little") + int(bool(saturates)).to_bytes(8, "little"))
+                image.tofile(f)
+            os.replace(tmp, self.path)
+        except OSError:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
 
 
 def main(argv=None):

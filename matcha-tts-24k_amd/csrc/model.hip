@@ -113,6 +113,8 @@ struct Packer {
     std::string why;
     int kq = GEMM_BK;          // K padding per tap of the panels being packed: 64 for the estimator in the 16-bit storage mode
     bool h16 = false;          // ... which also get the single fp16 plane (Panel::wh16)
+    bool dry = false;          // layout only: offsets and sizes are computed (the registered tensors are still checked for presence and
+                               // shape), nothing but zeros is written: mtts_import_weights takes the image itself from a cache
     explicit Packer(mtts_ctx* ctx) : c(ctx) {}
     const std::vector<float>* get(const std::string& key, size_t numel) {
         auto it = c->raw.find(key);
@@ -135,7 +137,7 @@ struct Packer {
         if (!t) return v;
         v.off = alloc(n);
         v.n = n;
-        std::memcpy(&c->image[v.off], t->data(), n * sizeof(float));
+        if (!dry) std::memcpy(&c->image[v.off], t->data(), n * sizeof(float));
         return v;
     }
     // Folded padding (kernels.h GnApplyArgs::bias_stats): where every input tap of a conv is a masked (zero) frame its output
@@ -145,6 +147,7 @@ struct Packer {
         Vec v;
         v.off = alloc(2 * G);
         v.n = 2 * G;
+        if (dry) return v;
         const int cpg = p.N / G;
         for (int g = 0; g < G; ++g) {
             double m = 0.0, q = 0.0;
@@ -168,17 +171,17 @@ struct Packer {
         const size_t n = (size_t)round_up(p.N, GEMM_BN) * p.ntaps * p.ktap;
         p.w16 = alloc((3 * n + 1) / 2);
         if (c->gemm_terms == 2) {
-            for (size_t i = 0; i < n; ++i)
+            for (size_t i = 0; i < n && !dry; ++i)
                 if (std::fabs(c->image[p.w + i]) > 65504.f) { c->weights_saturate = true; break; }
-            split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+            if (!dry) split_panel_f16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
             const int Np = round_up(p.N, GEMM_BN);
             const size_t Kp = (size_t)p.ntaps * p.ktap;
             p.wsum = alloc(Np);
             if (h16) {            // 16-bit storage mode: the fp16 head plane alone + row sums of the ROUNDED weights (LN epilogue)
                 p.wh16 = alloc((n + 1) / 2);
-                panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
+                if (!dry) panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
             }
-            for (int r = 0; r < Np; ++r) {
+            for (int r = 0; r < Np && !dry; ++r) {
                 double acc = 0.0;
                 for (size_t k = 0; k < Kp; ++k) {
                     const float w = c->image[p.w + (size_t)r * Kp + k];
@@ -186,7 +189,7 @@ struct Packer {
                 }
                 c->image[p.wsum + r] = (float)acc;
             }
-        } else split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
+        } else if (!dry) split_panel_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.w16]));
     }
     // a panel from explicit host data (rearranged / synthesised weights)
     Panel panel_from(const float* w, const float* bias, int kind, int N, int C, int ntaps) {
@@ -196,8 +199,8 @@ struct Packer {
         const size_t Kp = (size_t)ntaps * p.ktap;
         p.w = alloc((size_t)Np * Kp);
         p.b = alloc(Np);
-        pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w], p.ktap);
-        if (bias) { p.has_bias = true; std::memcpy(&c->image[p.b], bias, N * sizeof(float)); }
+        if (!dry) pack_weight_host(w, kind, N, C, ntaps, 0, nullptr, nullptr, &c->image[p.w], p.ktap);
+        if (bias) { p.has_bias = true; if (!dry) std::memcpy(&c->image[p.b], bias, N * sizeof(float)); }
         add_planes(p);
         return p;
     }
@@ -220,12 +223,13 @@ struct Packer {
         for (int part = 0; part < parts; ++part) {
             const auto* w = get(wkeys[part], per);
             if (!w) return p;
-            pack_weight_host(w->data(), kind, N_each, C, ntaps, kT, tsel, col_scale ? col_scale->data() : nullptr, tmp.data(), p.ktap);
-            std::memcpy(&c->image[p.w + (size_t)part * N_each * Kp], tmp.data(), (size_t)N_each * Kp * sizeof(float));
             const bool hb = part < (int)bkeys.size() && !bkeys[part].empty();
             const std::vector<float>* b = hb ? get(bkeys[part], N_each) : nullptr;
             if (hb && !b) return p;
             if (hb || col_shift) p.has_bias = true;
+            if (dry) continue;
+            pack_weight_host(w->data(), kind, N_each, C, ntaps, kT, tsel, col_scale ? col_scale->data() : nullptr, tmp.data(), p.ktap);
+            std::memcpy(&c->image[p.w + (size_t)part * N_each * Kp], tmp.data(), (size_t)N_each * Kp * sizeof(float));
             for (int n = 0; n < N_each; ++n) {
                 double acc = b ? (double)(*b)[n] : 0.0;
                 if (col_shift) {   // LayerNorm beta folded through the projection: b' = b + W . beta
@@ -239,11 +243,12 @@ struct Packer {
     }
 };
 
-static int pack_all(mtts_ctx* c) {
+static int pack_all(mtts_ctx* c, bool dry = false) {
     const mtts_config& g = c->cfg;
     c->image.clear();
     c->weights_saturate = false;
     Packer P(c);
+    P.dry = dry;
     auto S = [](const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; };
     const int taps3[3] = {-1, 0, 1};
     (void)taps3;
@@ -389,7 +394,7 @@ static int pack_all(mtts_ctx* c) {
             const auto* w = P.get(mlp_w[i], (size_t)mlp_n[i] * temb);
             const auto* b = P.get(mlp_b[i], mlp_n[i]);
             if (!w || !b) break;
-            for (int n = 0; n < mlp_n[i]; ++n) {
+            for (int n = 0; n < mlp_n[i] && !dry; ++n) {
                 std::memcpy(&c->image[p.w + (size_t)(D.res[i].tb_off + n) * p.ktap], &(*w)[(size_t)n * temb], temb * sizeof(float));
                 c->image[p.b + D.res[i].tb_off + n] = (*b)[n];
             }
@@ -411,7 +416,7 @@ static int pack_all(mtts_ctx* c) {
             t.chain_nqkv = nq;
             t.next = nq ? (int)k + 1 : -1;
             t.chain = P.alloc((size_t)t.chain_frags * CHAIN_WAVES * 256);
-            chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
+            if (!dry) chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
                               nq ? &c->image[D.tb[k + 1].qkv.w] : nullptr, reinterpret_cast<uint16_t*>(&c->image[t.chain]),
                               &c->weights_saturate);
         }
@@ -1099,6 +1104,45 @@ int64_t mtts_weights_bytes(mtts_ctx* c) {
     if (!c) { set_error("null context"); return -1; }
     if (!c->packed && pack_all(c)) return -1;
     return (int64_t)(c->image.size() * sizeof(float));
+}
+
+// The packed image depends on the architecture, the arithmetic and the layout switches -- everything below, as one string: a
+// cache file written by mtts_export_weights is valid for a context with the same signature and the same checkpoint tensors.
+int mtts_weights_signature(mtts_ctx* c, char* buf, int64_t n) {
+    if (!c || !buf || n < 64) { set_error("mtts_weights_signature: bad argument"); return -1; }
+    const mtts_config& g = c->cfg;
+    const int v[] = {MTTS_ABI_VERSION, MTTS_IMAGE_REVISION, g.n_feats, g.n_spks, g.spk_emb_dim, g.n_vocab, g.enc_channels, g.enc_filter,
+                     g.enc_heads, g.enc_layers, g.enc_kernel, g.prenet_layers, g.prenet_kernel, g.dp_filter, g.dp_kernel, g.dp_layers,
+                     g.dec_levels, g.dec_channels[0], g.dec_channels[1], g.dec_channels[2], g.dec_channels[3], g.dec_head_dim, g.dec_heads,
+                     g.dec_n_blocks, g.dec_mid_blocks, c->gemm_terms, c->half16, c->fast16, c->p16_on, c->chain_on, c->chain_ch};
+    std::string sig = "mtts";
+    for (int x : v) sig += "-" + std::to_string(x);
+    if ((int64_t)sig.size() + 1 > n) { set_error("mtts_weights_signature: buffer too small"); return -1; }
+    std::memcpy(buf, sig.c_str(), sig.size() + 1);
+    return (int)sig.size();
+}
+int mtts_export_weights(mtts_ctx* c, void* h_dst, int64_t bytes, int* saturates) {
+    if (!c || !h_dst) { set_error("mtts_export_weights: bad argument"); return -1; }
+    if (!c->packed && pack_all(c)) return -1;
+    if ((size_t)bytes < c->image.size() * sizeof(float)) { set_error("mtts_export_weights: buffer too small"); return -1; }
+    std::memcpy(h_dst, c->image.data(), c->image.size() * sizeof(float));
+    if (saturates) *saturates = c->weights_saturate ? 1 : 0;
+    return 0;
+}
+// Adopt an image exported earlier by a context of the same signature over the same tensors: the layout pass runs (offsets, sizes,
+// presence and shape of every registered tensor), the ~7 s of splitting and fragment packing do not.
+int mtts_import_weights(mtts_ctx* c, const void* h_src, int64_t bytes, int saturates) {
+    if (!c || !h_src) { set_error("mtts_import_weights: bad argument"); return -1; }
+    if (pack_all(c, true)) return -1;
+    if ((size_t)bytes != c->image.size() * sizeof(float)) {
+        c->packed = false;
+        set_error("mtts_import_weights: the image does not have this context's size (other architecture / arithmetic / library?)");
+        return -1;
+    }
+    std::memcpy(c->image.data(), h_src, (size_t)bytes);
+    c->weights_saturate = saturates != 0;
+    c->uploaded = false;
+    return 0;
 }
 
 int mtts_upload_weights(mtts_ctx* c, void* d_weights, int64_t bytes) {

@@ -222,6 +222,7 @@ def load_matcha(model_name, checkpoint_path):
         hp, sd = ck.load_converted(checkpoint_path)
         model = MatchaTTSInfer(**hp.as_reference_kwargs())
         model.load_state_dict(sd, strict=True)
+        model._rt.cache_dir = checkpoint_path        # the packed weight image is cached beside the converted tensors
     else:
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         hparams = dict(_plain(ckpt["hyper_parameters"]))
@@ -317,11 +318,51 @@ def pipeline(model, vocoder, text, speaker=0, voice_mix=None, n_timesteps=DEFAUL
     return waveform, to_waveform(out["encoder_mel"], vocoder), pairs
 
 
-def convert_to_mp3(waveform):  # pragma: no cover - post-waveform codec, out of the path's scope
-    from matcha.utils.mp3_converter import encode_mp3  # type: ignore
+def convert_to_mp3(waveform):
+    """reference inference.py:290-298: int16 PCM -> MP3 through the reference installation's LAME binding
+    (matcha.utils.mp3_converter.encode_mp3, vbr_quality=5, algorithm_quality=5).  The codec is a post-waveform CPU step outside
+    the synthesis path: it is delegated, not re-implemented, and raises ImportError where the reference
+    package (and its lameenc dependency) is not installed."""
+    import time
     import numpy as np
-    return encode_mp3((waveform.numpy() * 32767).astype(np.int16), SAMPLE_RATE)
+    from matcha.utils.mp3_converter import encode_mp3  # type: ignore
+    start = time.perf_counter()
+    audio_np = (waveform.detach().cpu().numpy() * 32767).astype(np.int16)
+    wav_size = audio_np.size * 2
+    mp3_data = encode_mp3(audio_np, sample_rate=SAMPLE_RATE, vbr_quality=5, algorithm_quality=5)
+    pct = (len(mp3_data) / wav_size * 100) if wav_size > 0 else 0
+    print(f"MP3 conversion: {(time.perf_counter() - start) * 1000:.1f}ms | {pct:.0f}% size")
+    return mp3_data
 
 
-def convert_to_opus_ogg(waveform):  # pragma: no cover - post-waveform codec, out of the path's scope
-    raise NotImplementedError("OGG/Opus encoding (PyAV) is outside the synthesis path; use the reference's encoder")
+def convert_to_opus_ogg(waveform):
+    """reference inference.py:301-322: int16 mono PCM -> Ogg/Opus with PyAV (libopus, 48 kbit/s, compression_level 5), the
+    reference's own settings and call sequence.  PyAV is imported here, as the reference imports it at module load; where it is
+    not installed the ImportError says so (no silent fallback)."""
+    import io
+    import time
+    import numpy as np
+    try:
+        import av  # type: ignore
+    except ImportError as e:
+        raise ImportError("convert_to_opus_ogg needs PyAV (`av`), as the reference's matcha/inference.py does") from e
+    start = time.perf_counter()
+    audio_np = (waveform.detach().cpu().numpy() * 32767).astype(np.int16).reshape(1, -1)
+    wav_size = audio_np.size * 2
+    buffer = io.BytesIO()
+    container = av.open(buffer, mode="w", format="ogg")
+    stream = container.add_stream("libopus", rate=SAMPLE_RATE)
+    stream.layout = "mono"
+    stream.bit_rate = 48000
+    stream.options = {"compression_level": "5"}
+    frame = av.AudioFrame.from_ndarray(audio_np, format="s16", layout="mono")
+    frame.sample_rate = SAMPLE_RATE
+    for packet in stream.encode(frame):
+        container.mux(packet)
+    for packet in stream.encode():
+        container.mux(packet)
+    container.close()
+    ogg_data = buffer.getvalue()
+    pct = (len(ogg_data) / wav_size * 100) if wav_size > 0 else 0
+    print(f"OGG conversion: {(time.perf_counter() - start) * 1000:.1f}ms | {pct:.0f}% size")
+    return bytes(ogg_data)

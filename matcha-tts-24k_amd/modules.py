@@ -52,6 +52,7 @@ class Runtime:
         self.use_wide = False
         self.dirty = True
         self.mel_mean, self.mel_std = hp.mel_mean, hp.mel_std
+        self.cache_dir = None       # a converted checkpoint's directory: the packed weight image is cached there (checkpoint.packed_cache)
 
     def _load(self, hip: HipModel) -> None:
         p = next(self.owner.parameters())
@@ -59,7 +60,7 @@ class Runtime:
             raise RuntimeError("matcha-tts-24k_amd: the model must be on a HIP device (model.to('cuda')); "
                                "there is no CPU path")
         sd = self.owner.state_dict()
-        hip.load_state_dict(sd, p.device)
+        hip.load_state_dict(sd, p.device, cache_dir=self.cache_dir)
         # denormalisation constants come from the checkpoint's buffers (reference inference.py:54-55,172)
         self.mel_mean, self.mel_std = float(sd["mel_mean"]), float(sd["mel_std"])
 
