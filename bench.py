@@ -70,7 +70,9 @@ GEMM_MODES = {0: ("f32", "v_mfma_f32_32x32x2_f32 on fp32 operands", 1, PEAK_F32_
               6: ("f32 via 3-term bf16 split (fp32 accumulate)", "v_mfma_f32_32x32x16_bf16, 6 products per MAC", 6, PEAK_16BIT_MFMA_TFLOPS),
               3: ("f32 via 2-term bf16 split (fp32 accumulate, ~2^-17 per product)", "v_mfma_f32_32x32x16_bf16, 3 products per MAC", 3, PEAK_16BIT_MFMA_TFLOPS),
               16: ("f16 storage, fp32 accumulate (BASELINE configs[2] arithmetic: 2-byte activation / weight planes; text encoder fp32-equivalent)",
-                   "v_mfma_f32_16x16x32_f16 / 32x32x16_f16, 1 product per MAC", 1, PEAK_16BIT_MFMA_TFLOPS)}
+                   "v_mfma_f32_16x16x32_f16 / 32x32x16_f16, 1 product per MAC", 1, PEAK_16BIT_MFMA_TFLOPS),
+              17: ("bf16 storage, fp32 accumulate (BASELINE configs[2] dtype: 2-byte bfloat16 activation / weight planes; text encoder fp32-equivalent)",
+                   "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, 1 product per MAC", 1, PEAK_16BIT_MFMA_TFLOPS)}
 BATCH, N_TOKENS, N_STEPS_ODE, SOLVER = 32, 128, 10, "euler"
 
 
@@ -166,14 +168,17 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default 32 = BASELINE configs[1]; other values are labelled)")
     ap.add_argument("--with-vocoder", action="store_true",
                     help="NON-DEFAULT: append the Vocos-24k head (random-init weights) to every step: mel -> waveform (configs[3] style)")
-    ap.add_argument("--arithmetic", default=None, choices=["f32", "f16-storage"],
-                    help="f32 (default): fp32-equivalent split arithmetic = configs[1]; f16-storage: BASELINE configs[2]'s 16-bit storage "
-                         "mode (per-rank shape of the 8-way job: 32 utterances per GPU), labelled with its measured mel error")
+    ap.add_argument("--arithmetic", default=None, choices=["f32", "f16-storage", "bf16-storage"],
+                    help="f32 (default): fp32-equivalent split arithmetic = configs[1]; f16-storage / bf16-storage: BASELINE configs[2]'s "
+                         "16-bit storage mode with fp16 / bfloat16 planes (per-rank shape of the 8-way job: 32 utterances per GPU), labelled "
+                         "with its measured mel error")
     ap.add_argument("--solver", default=SOLVER)
     ap.add_argument("--n-timesteps", type=int, default=N_STEPS_ODE)
     args = ap.parse_args()
     if args.arithmetic == "f16-storage":
         os.environ["MTTS_GEMM_TERMS"] = "16"
+    elif args.arithmetic == "bf16-storage":
+        os.environ["MTTS_GEMM_TERMS"] = "17"
     default_cfg = (args.batch, args.solver, args.n_timesteps) == (BATCH, SOLVER, N_STEPS_ODE) and not args.with_vocoder
     BATCH, SOLVER, N_STEPS_ODE = args.batch, args.solver, args.n_timesteps
 
@@ -286,9 +291,13 @@ def main():
         _, instr, products, hw_peak = GEMM_MODES[terms]
         peak = hw_peak / products      # fp32-equivalent peak: every algorithmic MAC costs `products` MFMA MACs
         roofline = {
-            "bound": "mfma", "kernel": "gemm_p16_kernel + gemm_f32_kernel (GEMM / implicit conv1d, all instantiations)",
+            "bound": "mfma", "kernel": "gemm_p16_kernel + tblock_chain_kernel + gemm_f32_kernel (GEMM / implicit conv1d / transformer-block chain, all instantiations)",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
+            "frac": round(achieved / peak, 4),
+            # the whole step against the same peak: every executed GEMM + attention FLOP over the TIMED step (launch gaps, attention,
+            # streaming kernels, the text encoder and the host included), not only the time inside GEMM kernels
+            "frac_whole_step": round((fl_g + fl_a) / args.steps / (el / args.steps) / 1e12 / peak, 4),
+            "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
             "peak_basis": f"{hw_peak:.0f} TFLOP/s dense ({instr}) / {products}",
             "mfma_executed_tflops": round(achieved * products, 1),
             "algorithmic_mb_per_launch": round(by_g / max(n_g, 1) / 1e6, 2),
@@ -308,7 +317,7 @@ def main():
         }
 
     precision = None
-    if rank == 0 and terms in (1, 16):
+    if rank == 0 and terms in (1, 16, 17):
         # reduced-precision arithmetic: its mel error against this library's fp32-equivalent path (itself 4e-5 from the
         # reference goldens, tests/test_hip_path.py) on the first utterances of the batch, same ids and the same noise
         nb = min(4, BATCH)
@@ -345,7 +354,7 @@ def main():
                        "n_feats": hp.n_feats, "note": "the reference fork uses 100 mel bins (Vocos-24k), not 80"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if terms == 16:
+        if terms in (16, 17):
             line["config"]["workload"] = ("per-rank shape of configs[2] (batch=256 sharded 8-way = 32 utterances per GPU, n_timesteps=10, 16-bit "
                                           "storage / fp32 accumulate) -- NOT the fp32 headline; " + line["config"]["workload"])
         if precision is not None:

@@ -287,6 +287,9 @@ int mtts_vocos_decode(mtts_vocos* v, const float* d_mel, int B, int T, float* d_
  * planes (2 bytes per element, half the operand traffic), one MFMA per multiply-accumulate, fp32 accumulation, fp32
  * GroupNorm / LayerNorm statistics and ODE state; the text encoder and duration predictor keep the fp32-equivalent split
  * (durations must not move).  Not inside the 1e-3 bar: its measured mel error is reported beside its throughput.
+ * 17 = the same mode with BFLOAT16 planes (the dtype BASELINE config #3 names): same layout and traffic, bf16 MFMAs, the fp32
+ * exponent range (no saturation, the range guard stays silent), 8 significand bits per operand instead of 11 -- the reference's
+ * own bf16 autocast deviates ~8x more from its fp32 mel than its fp16 autocast (tests/golden/prod_autocast.npz).
  * mtts_weights_saturate: 1 if a WEIGHT exceeds the fp16 range in the fp16-split mode (decided while packing). */
 int mtts_set_arithmetic(mtts_ctx* ctx, int terms);
 int mtts_weights_saturate(mtts_ctx* ctx);
@@ -294,7 +297,7 @@ int mtts_weights_saturate(mtts_ctx* ctx);
 /* ---------------------------------------------------------------- measurement */
 
 /* GEMM arithmetic of a context (NULL: the library default): 0 native fp32 MFMA, 2 fp16 two-term split (default),
- * 6 bf16 three-term split, 3 bf16 two-term split -- see mtts_gemm_f32; 1 / 16 = the fp16 modes of mtts_set_arithmetic. */
+ * 6 bf16 three-term split, 3 bf16 two-term split -- see mtts_gemm_f32; 1 / 16 / 17 = the 16-bit modes of mtts_set_arithmetic. */
 int mtts_gemm_terms(mtts_ctx* ctx);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline line).

@@ -53,9 +53,17 @@ __device__ __forceinline__ f16x4 tr_read4(const _Float16* lds_ptr) {
 
 // ONE (with P16): the opt-in fp16 mode -- heads x heads products only (see gemm_p16.hip).
 // HALF (with P16 and ONE): q|k|v and the output are H16 images (AttnArgs::half16) -- a head is 64 contiguous halves.
-template <int NW, bool P16, bool ONE = false, bool HALF = false>
+// BF (with HALF): the H16 images hold bfloat16 (AttnArgs::bf16): bf16 MFMAs, probabilities and outputs rounded to bfloat16.
+using bf16x8_a = __attribute__((ext_vector_type(8))) __bf16;
+template <bool BF>
+__device__ __forceinline__ f32x16 att_mfma(f16x8 a, f16x8 b, f32x16 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_a, a), __builtin_bit_cast(bf16x8_a, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <int NW, bool P16, bool ONE = false, bool HALF = false, bool BF = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
     static_assert(!HALF || (P16 && ONE), "H16 I/O runs the single-product loop");
+    static_assert(!BF || HALF, "bfloat16 planes exist in the 16-bit storage mode only");
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
     constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
                 }
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], s[t], 0, 0, 0);
+                s[t] = att_mfma<BF>(kh, qh[kb], s[t]);
             }
         }
         // ---- bias + online softmax.  Register r of sub-tile t is key 32t + (r&3) + 8(r>>2) + 4h.
@@ -286,12 +294,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 f16x8 ph, pl;
+                if constexpr (BF) {
+                    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+                    u32x4 w;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = s[t][8 * ks + j];
-                    const _Float16 a = (_Float16)pv;
-                    ph[j] = a;
-                    pl[j] = (_Float16)(pv - (float)a);
+                    for (int j = 0; j < 4; ++j) w[j] = pack_bf16(s[t][8 * ks + 2 * j], s[t][8 * ks + 2 * j + 1]);
+                    ph = __builtin_bit_cast(f16x8, w);
+                    pl = ph;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pv = s[t][8 * ks + j];
+                        const _Float16 a = (_Float16)pv;
+                        ph[j] = a;
+                        pl[j] = (_Float16)(pv - (float)a);
+                    }
                 }
                 const int k0 = 32 * t + 16 * ks + 4 * h;       // this lane half's keys: k0..k0+3 and k0+8..k0+11
 #pragma unroll
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
                     }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
+                    o[dt] = att_mfma<BF>(vh, ph, o[dt]);
                 }
             }
     }
@@ -325,6 +342,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     f16x4 hh, ll;
+                    if constexpr (BF) {
+                        using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                        *reinterpret_cast<u32x2*>(op + t * 32 + 8 * g4 + 4 * h) =
+                            u32x2{pack_bf16(o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv), pack_bf16(o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv)};
+                        continue;
+                    }
                     range_bad |= out_of_f16_range(o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv, o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const bool p16 = a.qkv16 != nullptr;
     const int ew = a.half16 ? 1 : 2;
-    if (a.half16 && !p16) return hipErrorInvalidValue;
+    if ((a.half16 && !p16) || (a.bf16 && !a.half16)) return hipErrorInvalidValue;
     if (p16 ? (!a.out16 || a.D != AT_D || a.ld16 < 3 * ew * a.H * AT_D || (a.ld16 & 7) || a.ldo16 < ew * a.H * AT_D || (a.ldo16 & 3))
             : (!a.qkv || !a.out))
         return hipErrorInvalidValue;
@@ -377,12 +400,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const bool same_rows = b128 * 128 == b64 * 64 && blocks128 >= 512;
     const bool use128 = env_nw == 4 || (env_nw == 0 && ((blocks128 >= 768 && waste128 < 0.1) || same_rows));
     if (use128) {
-        if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        if (a.half16 && a.bf16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
+        else if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (p16) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
     } else {
-        if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        if (a.half16 && a.bf16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
+        else if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else if (p16 && a.fast16) hipLaunchKernelGGL((attention_f32_kernel<2, true, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else if (p16) hipLaunchKernelGGL((attention_f32_kernel<2, true>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);
         else hipLaunchKernelGGL((attention_f32_kernel<2, false>), dim3(b64 * a.H * a.B), dim3(128), 0, s, a);

@@ -21,6 +21,17 @@ __device__ __forceinline__ void split_f16(float x, float lscale, _Float16& h, _F
     l = (_Float16)((xc - (float)h) * lscale);
 }
 
+// bfloat16 planes (GemmArgs::bf16): two values -> one packed word (v_cvt_pk_bf16_f32, round to nearest even), and back
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ void unpack_bf16(unsigned int w, float& a, float& b) {
+    a = __builtin_bit_cast(float, w << 16);
+    b = __builtin_bit_cast(float, w & 0xffff0000u);
+}
+
 // n / d by a host-made reciprocal (rcp = floor(2^32 / d) + 1; exact while n * d < 2^32).  rcp == 0 (wave-uniform) means "divide":
 // d <= 1, or a launch whose quotients could leave that range (the launcher decides, gemm_p16.hip rcp32)
 __device__ __forceinline__ int fdiv(int n, int d, unsigned int rcp) { return rcp ? (int)__umulhi((unsigned int)n, rcp) : (d <= 1 ? n : n / d); }

@@ -439,10 +439,10 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
     typedef __attribute__((address_space(1))) _Float16 ghalf;
     unsigned long long q_out = (unsigned long long)p.out, q_out16 = (unsigned long long)p.out16, q_stats = (unsigned long long)p.stats_out,
                        q_om = (unsigned long long)p.out_mask, q_om16 = (unsigned long long)p.out16_mask;
-    int a_ldc = p.ldc, a_ld16 = p.ld16, a_half = p.half16 ? 1 : 0, a_nw = p.N >> 6;
+    int a_ldc = p.ldc, a_ld16 = p.ld16, a_half = p.half16 ? 1 : 0, a_nw = p.N >> 6, a_bf = p.bf16 ? 1 : 0;
     float a_scale = p.out_scale, a_lscale = p.out_lscale;
     asm volatile("" : "+s"(q_out), "+s"(q_out16), "+s"(q_stats), "+s"(q_om), "+s"(q_om16));
-    asm volatile("" : "+s"(a_ldc), "+s"(a_ld16), "+s"(a_half), "+s"(a_nw), "+s"(a_scale), "+s"(a_lscale));
+    asm volatile("" : "+s"(a_ldc), "+s"(a_ld16), "+s"(a_half), "+s"(a_nw), "+s"(a_scale), "+s"(a_lscale), "+s"(a_bf));
     gfloat* const a_out = (gfloat*)q_out;
     ghalf* const a_out16 = (ghalf*)q_out16;
     gfloat* const a_stats = (gfloat*)q_stats;
@@ -621,7 +621,8 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
 #pragma unroll
                         for (int e2 = 0; e2 < 2; ++e2) {
                             float ra, rb;
-                            widen_pair(rh[2 * h + e2], rlw[2 * h + e2], ra, rb);
+                            if (a_bf) unpack_bf16(rh[2 * h + e2], ra, rb);          // (bfloat16 planes: one term)
+                            else widen_pair(rh[2 * h + e2], rlw[2 * h + e2], ra, rb);
                             o[h][2 * e2] += ra;
                             o[h][2 * e2 + 1] += rb;
                         }
@@ -641,7 +642,8 @@ __device__ __forceinline__ void gemm_epilogue_rows8(const GemmArgs& p, const Epi
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 unsigned int hp;
-                                split_pair<false>(o[k >> 1][2 * (k & 1)] * m16, o[k >> 1][2 * (k & 1) + 1] * m16, a_lscale, hp, lp, rmax);
+                                if (a_bf) hp = pack_bf16(o[k >> 1][2 * (k & 1)] * m16, o[k >> 1][2 * (k & 1) + 1] * m16);
+                                else split_pair<false>(o[k >> 1][2 * (k & 1)] * m16, o[k >> 1][2 * (k & 1) + 1] * m16, a_lscale, hp, lp, rmax);
                                 hv[k] = hp;
                             }
                             *(__attribute__((address_space(1))) u32x4_e*)(a_out16 + (size_t)L.orow[u] * a_ld16 + nc) = hv;

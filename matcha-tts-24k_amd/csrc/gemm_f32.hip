@@ -559,6 +559,12 @@ void panel_h16_host(const float* panel, size_t n, uint16_t* plane) {
         memcpy(&plane[i], &h, 2);
     }
 }
+void panel_bf16_host(const float* panel, size_t n, uint16_t* plane) {
+    for (size_t i = 0; i < n; ++i) {
+        const __bf16 h = (__bf16)panel[i];
+        memcpy(&plane[i], &h, 2);
+    }
+}
 void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes) {
     for (size_t i = 0; i < n; ++i) {
         const float x = panel[i];

@@ -44,6 +44,19 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// one 16-bit MFMA on raw 16-byte operand fragments: fp16 or (BF) bfloat16 planes
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma16_raw(f16x8 a, f16x8 b, f32x4 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma32_raw(f16x8 a, f16x8 b, f32x16 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __attribute__((aligned(128))) _Float16 g_p16_zero_line[64];     // source of out-of-range conv taps (zero-initialised)
 
@@ -78,7 +91,8 @@ template <int BM, bool LN, int NST, int MODE, bool M16, bool GN = false, int KS 
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(const GemmArgs p) {
     static_assert(!(GN && LN), "GroupNorm statistics come from conv GEMMs, which have no LayerNorm prologue");
     constexpr bool ONE = MODE == 1;
-    constexpr bool HALF = MODE == 2;
+    constexpr bool HALF = MODE == 2 || MODE == 3;          // MODE 3: the H16 planes hold bfloat16 (GemmArgs::bf16)
+    constexpr bool BF = MODE == 3;
     constexpr int KSTEP = HALF ? 64 : 32;                  // k elements per 128-byte line
     constexpr int APW = BM / 32;           // A pieces (8 rows x 128 B) a wave moves per k-step; W: 4 per wave
     constexpr int STAGE = p16_stage_bytes(BM);
@@ -223,12 +237,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
 #pragma unroll
                 for (int j = 0; j < JB; ++j) {
                     if constexpr (HALF) {          // second 32-k half of the line
-                        acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bl[j], acc[i][j0 + j], 0, 0, 0);
+                        acc[i][j0 + j] = mfma16_raw<BF>(al[i], bl[j], acc[i][j0 + j]);
                     } else if constexpr (!ONE) {
                         accx[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j0 + j], 0, 0, 0);
                         accx[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j0 + j], 0, 0, 0);
                     }
-                    acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j0 + j], 0, 0, 0);
+                    acc[i][j0 + j] = mfma16_raw<BF>(ah[i], bh[j], acc[i][j0 + j]);
                 }
         }
     };
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
                         accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx32[i][j], 0, 0, 0);
                         accx32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx32[i][j], 0, 0, 0);
                     }
-                    acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc32[i][j], 0, 0, 0);
+                    acc32[i][j] = mfma32_raw<BF>(ah[i], bh[j], acc32[i][j]);
                 }
         }
     };
@@ -547,6 +561,7 @@ static hipError_t launch_p16_one(const GemmArgs& a, hipStream_t s) {
 
 template <int BM, bool LN, int NST = 2>
 static hipError_t launch_p16_variant(const GemmArgs& a, hipStream_t s) {
+    if (a.half16 && a.bf16) return launch_p16_one<BM, LN, NST, 3>(a, s);
     if (a.half16) return launch_p16_one<BM, LN, NST, 2>(a, s);
     return a.fast16 ? launch_p16_one<BM, LN, NST, 1>(a, s) : launch_p16_one<BM, LN, NST, 0>(a, s);
 }
@@ -616,6 +631,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
     if (a.out16 && ((a.N % 32) || a.ld16 < ew * a.N || (a.ld16 & 3))) return hipErrorInvalidValue;
     if (a.stats_out && (a.N & 63)) return hipErrorInvalidValue;
     if (a.act == ACT_SNAKE && (!a.p0 || !a.p1)) return hipErrorInvalidValue;
+    if (a.bf16 && !a.half16) return hipErrorInvalidValue;
     if (a.gn_stats && a.fast16) return hipErrorInvalidValue;          // (the opt-in fp16 mode keeps the separate statistics pass)
     if (a.gn_stats) {
         const bool plain = a.out_stride == 1 && a.out_off == 0 && a.out_T == a.T_out;
@@ -659,6 +675,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
         static const int splitk = [] { const char* e = getenv("MTTS_P16_SPLITK"); return e ? atoi(e) : 1; }();
         const int nk_all = a.ntaps * a.ktap / kq;
         if (nst == 4 && splitk && nk_all >= 4 && (nk_all % 2) == 0) {
+            if (a.half16 && a.bf16) return ln ? launch_p16_splitk<true, 3>(a, s) : launch_p16_splitk<false, 3>(a, s);
             if (a.half16) return ln ? launch_p16_splitk<true, 2>(a, s) : launch_p16_splitk<false, 2>(a, s);
             if (a.fast16) return ln ? launch_p16_splitk<true, 1>(a, s) : launch_p16_splitk<false, 1>(a, s);
             return ln ? launch_p16_splitk<true, 0>(a, s) : launch_p16_splitk<false, 0>(a, s);
@@ -674,7 +691,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ fp32 <-> P16
 __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mask, int M, int C, int C_valid,
-                              _Float16* __restrict__ out, int ld16, float lscale, unsigned int* range_flag, bool half16) {
+                              _Float16* __restrict__ out, int ld16, float lscale, unsigned int* range_flag, bool half16, bool bf16) {
     const int c4n = C >> 2;
     const size_t n = (size_t)M * c4n;
     bool range_bad = false;
@@ -692,7 +709,10 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
             h[e] = a;
             l[e] = b;
         }
-        if (half16) {
+        if (half16 && bf16) {
+            using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+            *reinterpret_cast<u32x2*>(out + (size_t)row * ld16 + c) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        } else if (half16) {
             *reinterpret_cast<f16x4*>(out + (size_t)row * ld16 + c) = h;
         } else {
             _Float16* o = out + (size_t)row * ld16 + (c >> 5) * 64 + (c & 31);
@@ -700,16 +720,16 @@ __global__ void to_p16_kernel(const float* __restrict__ x, int ld, const float* 
             *reinterpret_cast<f16x4*>(o + 32) = l;
         }
     }
-    raise_range_flag(range_flag, range_bad);
+    raise_range_flag(range_flag, range_bad && !bf16);
 }
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s, unsigned int* range_flag, bool half16) {
+                         hipStream_t s, unsigned int* range_flag, bool half16, bool bf16) {
     if (!x || !out || M <= 0 || C <= 0 || (C % 32) || (ld & 3) || C_valid > C || (C_valid & 3) || ld < C_valid || ld16 < (half16 ? 1 : 2) * C || (ld16 & 3))
         return hipErrorInvalidValue;
     const size_t n = (size_t)M * (C >> 2);
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale, range_flag, half16);
+    hipLaunchKernelGGL(to_p16_kernel, dim3(grid), dim3(256), 0, s, x, ld, mask, M, C, C_valid, out, ld16, lscale, range_flag, half16, bf16);
     return hipGetLastError();
 }
 __global__ void from_p16_kernel(const _Float16* __restrict__ x, int ld16, int M, int C, float inv_lscale, float* __restrict__ out, int ld) {

@@ -98,6 +98,10 @@ struct GemmArgs {
     // w16h [Np][Kp] halves, and a MAC is one v_mfma_f32_16x16x32_f16 with fp32 accumulation.  Row strides stay in halves.
     bool half16 = false;
     const void* w16h = nullptr;
+    // the same mode with BFLOAT16 planes (mtts_set_arithmetic(ctx, 17): what BASELINE configs[2] names): identical layout and data
+    // movement, v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 on the planes, v_cvt_pk_bf16_f32 in the producers; the fp32 exponent
+    // range, so no range guard, 8 significand bits instead of 11
+    bool bf16 = false;
     // fp16-split arithmetic only: set to 1 (sticky, atomicOr) when an operand this launch splits -- an A element while staging
     // (gemm_f32.hip, terms 2) or an out16 element (epilogue) -- lies beyond +-65504 and saturates.  Null = no check.
     unsigned int* range_flag = nullptr;
@@ -114,7 +118,7 @@ hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by 
 int gemm_p16_wave_rows(const GemmArgs& a);                          // rows of a wave tile (BM/2) launch_gemm_p16 will use for these shapes
 // fp32 rows [M][ld] -> P16 image [M][ld16 halves] of channels [0, C) (C % 32 == 0), optionally times mask[row]
 hipError_t launch_to_p16(const float* x, int ld, const float* mask, int M, int C, int C_valid, _Float16* out, int ld16, float lscale,
-                         hipStream_t s, unsigned int* range_flag = nullptr, bool half16 = false);   // half16: H16 image, lscale unused   // channels [C_valid, C) are written as zeros
+                         hipStream_t s, unsigned int* range_flag = nullptr, bool half16 = false, bool bf16 = false);   // half16: H16 image, lscale unused   // channels [C_valid, C) are written as zeros
 hipError_t launch_from_p16(const _Float16* x, int ld16, int M, int C, float lscale, float* out, int ld, hipStream_t s);
 static inline double gemm_flops(const GemmArgs& a) {
     return 2.0 * double(a.B) * a.T_out * a.N * double(a.ntaps) * (a.c0 + a.c1);
@@ -138,6 +142,7 @@ void split_panel_host(const float* panel, size_t n, uint16_t* planes);
 hipError_t launch_split_panel(const float* panel, size_t n, void* planes, hipStream_t s);
 void split_panel_f16_host(const float* panel, size_t n, uint16_t* planes);
 void panel_h16_host(const float* panel, size_t n, uint16_t* plane);      // the fp16 head plane alone, same element order as the panel
+void panel_bf16_host(const float* panel, size_t n, uint16_t* plane);     // the same as bfloat16 (round to nearest even)
 hipError_t launch_split_panel_f16(const float* panel, size_t n, void* planes, hipStream_t s);
 
 struct AttnArgs {
@@ -157,6 +162,7 @@ struct AttnArgs {
     bool fast16 = false;          // P16 I/O only: single fp16 product per MAC (no residual terms)
     unsigned int* range_flag = nullptr;   // P16 output: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
     bool half16 = false;          // q|k|v and the output are H16 images (GemmArgs::half16): a head = 64 contiguous halves
+    bool bf16 = false;            // ... holding bfloat16 instead of fp16 values (GemmArgs::bf16)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 static inline double attn_flops(const AttnArgs& a) { return 4.0 * double(a.B) * a.H * double(a.T) * a.T * a.D; }
@@ -274,6 +280,7 @@ struct GnApplyArgs {
     int B = 0, T = 0, C = 0, G = 8; float eps = 1e-5f;
     unsigned int* range_flag = nullptr;   // out16: sticky flag for values beyond +-65504 (GemmArgs::range_flag)
     bool half16 = false;                  // out16 is an H16 image (GemmArgs::half16)
+    bool bf16 = false;                    // ... of bfloat16 values (GemmArgs::bf16)
 };
 hipError_t launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 

@@ -91,6 +91,7 @@ struct mtts_ctx {
     const int* d_tlen = nullptr;  // per-utterance frame limits of the next estimator calls (mtts_set_frame_limits), device [B]
     bool half16 = false;          // 16-bit storage mode (mtts_set_arithmetic(ctx, 16) / MTTS_GEMM_TERMS=16): the estimator's images are
                                   // single fp16 planes, one MFMA per MAC (BASELINE config #3); everything else as for terms 2
+    bool bf16 = false;            // ... with bfloat16 planes (mtts_set_arithmetic(ctx, 17) / MTTS_GEMM_TERMS=17; half16 is set as well)
     bool half_now = false;        // set while the estimator's launches are being enqueued in that mode
     bool fast16 = false;          // MTTS_GEMM_TERMS=1 at mtts_create: the estimator's P16 kernels multiply the fp16 heads only
     bool p16_on = true;           // fp16-split mode: activations as P16 images between kernels (MTTS_P16=0 at mtts_create disables)

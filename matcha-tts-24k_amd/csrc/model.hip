@@ -58,6 +58,7 @@ static int run_gemm(mtts_ctx* c, const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.range_flag = c->cur_flag;
     a.half16 = c->half_now && a.a16_0 != nullptr;
+    a.bf16 = a.half16 && c->bf16;
     LAUNCHB(c, 0, gemm_flops(a), gemm_bytes(a), s, launch_gemm(a, s));
     return 0;
 }
@@ -65,6 +66,7 @@ static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.range_flag = c->cur_flag;
     a.half16 = c->half_now && a.qkv16 != nullptr;
+    a.bf16 = a.half16 && c->bf16;
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
@@ -78,6 +80,7 @@ static int run_gn_apply(mtts_ctx* c, const GnApplyArgs& a0, hipStream_t s) {
     GnApplyArgs a = a0;
     a.range_flag = c->cur_flag;
     a.half16 = c->half_now && a.out16 != nullptr;
+    a.bf16 = a.half16 && c->bf16;
     LAUNCH(c, 2, 0, s, launch_gn_apply(a, s));
     return 0;
 }
@@ -179,13 +182,14 @@ struct Packer {
             p.wsum = alloc(Np);
             if (h16) {            // 16-bit storage mode: the fp16 head plane alone + row sums of the ROUNDED weights (LN epilogue)
                 p.wh16 = alloc((n + 1) / 2);
-                if (!dry) panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
+                if (!dry && c->bf16) panel_bf16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
+                else if (!dry) panel_h16_host(&c->image[p.w], n, reinterpret_cast<uint16_t*>(&c->image[p.wh16]));
             }
             for (int r = 0; r < Np && !dry; ++r) {
                 double acc = 0.0;
                 for (size_t k = 0; k < Kp; ++k) {
                     const float w = c->image[p.w + (size_t)r * Kp + k];
-                    acc += h16 ? (double)(float)(_Float16)fminf(fmaxf(w, -65504.f), 65504.f) : (double)w;
+                    acc += !h16 ? (double)w : c->bf16 ? (double)(float)(__bf16)w : (double)(float)(_Float16)fminf(fmaxf(w, -65504.f), 65504.f);
                 }
                 c->image[p.wsum + r] = (float)acc;
             }
@@ -913,7 +917,7 @@ static int decoder_eval_p16(mtts_ctx* c, DecBufs& d, const float* xin, int ev, c
     const float* tb = d.TB + (size_t)ev * D.tb_total;
     size_t ri = 0, ti = 0;
     // masked x | mu | zero padding as a P16 image (reference decoder.py:379: the first ResNet sees x * mask)
-    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, d.ew * d.ldx, 2048.0f, s, c->cur_flag, d.ew == 1));
+    LAUNCH(c, 2, 0, s, launch_to_p16(xin, d.ldx, d.mask[0], B * d.T, d.ldx, 2 * g.n_feats, d.XM16, d.ew * d.ldx, 2048.0f, s, c->cur_flag, d.ew == 1, d.ew == 1 && c->bf16));
     const _Float16* cur = d.XM16;
     int cur_c = d.ldx;
     // ---- down path
@@ -1057,7 +1061,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     mtts_ctx* c = new mtts_ctx();
     c->cfg = g;
     c->gemm_terms = default_gemm_terms();
-    { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; c->half16 = e && atoi(e) == 16; }   // 1 / 16: fp16 modes (include/mtts.h)
+    { const char* e = getenv("MTTS_GEMM_TERMS"); c->fast16 = e && atoi(e) == 1; c->half16 = e && (atoi(e) == 16 || atoi(e) == 17); c->bf16 = e && atoi(e) == 17; }   // 1 / 16 / 17: 16-bit modes (include/mtts.h)
     { const char* e = getenv("MTTS_P16"); c->p16_on = !(e && e[0] == '0'); }
     { const char* e = getenv("MTTS_CHAIN"); c->chain_on = !(e && e[0] == '0'); }
     { const char* e = getenv("MTTS_CHAIN_CH"); c->chain_ch = (e && atoi(e) == 128) ? 128 : 256; }
@@ -1068,13 +1072,14 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
 
 int mtts_set_arithmetic(mtts_ctx* c, int terms) {
     if (!c) { set_error("null context"); return -1; }
-    if (terms != 0 && terms != 1 && terms != 2 && terms != 3 && terms != 6 && terms != 16) {
-        set_error("mtts_set_arithmetic: terms must be 0, 1, 2, 3, 6 or 16");
+    if (terms != 0 && terms != 1 && terms != 2 && terms != 3 && terms != 6 && terms != 16 && terms != 17) {
+        set_error("mtts_set_arithmetic: terms must be 0, 1, 2, 3, 6, 16 or 17");
         return -1;
     }
     c->fast16 = terms == 1;
-    c->half16 = terms == 16;
-    c->gemm_terms = (terms == 1 || terms == 16) ? 2 : terms;
+    c->half16 = terms == 16 || terms == 17;
+    c->bf16 = terms == 17;
+    c->gemm_terms = (terms == 1 || terms == 16 || terms == 17) ? 2 : terms;
     c->packed = false;
     c->uploaded = false;
     return 0;
@@ -1114,7 +1119,7 @@ int mtts_weights_signature(mtts_ctx* c, char* buf, int64_t n) {
     const int v[] = {MTTS_ABI_VERSION, MTTS_IMAGE_REVISION, g.n_feats, g.n_spks, g.spk_emb_dim, g.n_vocab, g.enc_channels, g.enc_filter,
                      g.enc_heads, g.enc_layers, g.enc_kernel, g.prenet_layers, g.prenet_kernel, g.dp_filter, g.dp_kernel, g.dp_layers,
                      g.dec_levels, g.dec_channels[0], g.dec_channels[1], g.dec_channels[2], g.dec_channels[3], g.dec_head_dim, g.dec_heads,
-                     g.dec_n_blocks, g.dec_mid_blocks, c->gemm_terms, c->half16, c->fast16, c->p16_on, c->chain_on, c->chain_ch};
+                     g.dec_n_blocks, g.dec_mid_blocks, c->gemm_terms, c->half16, c->bf16, c->fast16, c->p16_on, c->chain_on, c->chain_ch};
     std::string sig = "mtts";
     for (int x : v) sig += "-" + std::to_string(x);
     if ((int64_t)sig.size() + 1 > n) { set_error("mtts_weights_signature: buffer too small"); return -1; }
@@ -1705,7 +1710,7 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
 }
 
 // ------------------------------------------------------------------------------------------------ measurement
-int mtts_gemm_terms(mtts_ctx* c) { return c ? (c->half16 ? 16 : c->fast16 ? 1 : c->gemm_terms) : default_gemm_terms(); }
+int mtts_gemm_terms(mtts_ctx* c) { return c ? (c->bf16 ? 17 : c->half16 ? 16 : c->fast16 ? 1 : c->gemm_terms) : default_gemm_terms(); }
 
 int mtts_prof_enable(mtts_ctx* c, int on) {
     if (!c) { set_error("null context"); return -1; }

@@ -349,7 +349,7 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
             if (p.out) *reinterpret_cast<f32x4*>(p.out + row[u] * p.C + c4 * 4) = o;
             if (p.out16) {       // P16 image for the next GEMM's LDS-DMA (gemm_p16.hip)
                 f16x4 hh, ll;
-                range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && m16[u] != 0.f;
+                range_bad |= out_of_f16_range(o[0], o[1], o[2], o[3]) && m16[u] != 0.f && !p.bf16;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     _Float16 a, b;
@@ -357,7 +357,11 @@ __global__ void gn_apply_kernel(const GnApplyArgs p) {
                     hh[e] = a;
                     ll[e] = b;
                 }
-                if (p.half16) {
+                if (p.half16 && p.bf16) {
+                    using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                    *reinterpret_cast<u32x2*>(p.out16 + row[u] * (size_t)p.ld16 + c4 * 4) =
+                        u32x2{pack_bf16(o[0] * m16[u], o[1] * m16[u]), pack_bf16(o[2] * m16[u], o[3] * m16[u])};
+                } else if (p.half16) {
                     *reinterpret_cast<f16x4*>(p.out16 + row[u] * (size_t)p.ld16 + c4 * 4) = hh;
                 } else {
                     _Float16* o16 = p.out16 + row[u] * (size_t)p.ld16 + (c4 >> 3) * 64 + (c4 & 7) * 4;

@@ -111,7 +111,7 @@ class MatchaTTSInfer(nn.Module):
         if rt.use_wide:                       # a previous call or the weights already needed the wide arithmetic
             return self._synthesise(*args)
         hip = rt.ready()
-        if hip.gemm_terms() not in (1, 2, 16) or self.range_policy == "ignore":     # only the fp16-based arithmetics saturate
+        if hip.gemm_terms() not in (1, 2, 16, 17) or self.range_policy == "ignore":     # only the fp16-based arithmetics saturate (17: the text encoder's)
             return self._synthesise(*args)
         saturated = hip.weights_saturate()
         out = None

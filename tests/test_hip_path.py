@@ -587,12 +587,12 @@ def test_graph_cache_follows_weight_reload(hparams, synthetic, dev):
 
 
 # ------------------------------------------------------------------------------------------------ 16-bit storage mode (config #3)
-def _half_model(hp, sd, dev, monkeypatch):
-    monkeypatch.setenv("MTTS_GEMM_TERMS", "16")
+def _half_model(hp, sd, dev, monkeypatch, terms=16):
+    monkeypatch.setenv("MTTS_GEMM_TERMS", str(terms))
     m = make_model(hp, sd, dev)
     m.hip                                   # the context reads the variable when it is created
     monkeypatch.delenv("MTTS_GEMM_TERMS")
-    assert m.hip.gemm_terms() == 16
+    assert m.hip.gemm_terms() == terms
     return m
 
 
@@ -655,27 +655,30 @@ def test_config3_per_rank_shape_half_storage(prod, synthetic, dev, monkeypatch):
     assert 1e-4 < err < 2.0 * anchor[0] and mean_err < 1.5 * anchor[1], (err, mean_err, anchor)
 
 
-def test_half_storage_mode_vs_reference_autocast_anchor(prod, synthetic, dev, monkeypatch):
-    """The 16-bit storage mode against the reference-derived anchor on the SAME inputs (prod_synth: Tx=128, euler/10, seed-42
-    noise): the reference's synthesise under torch.autocast(float16) -- what matcha/inference.py:238 runs -- deviates from its
-    fp32 mel by err_fp16 = (max, mean); the HIP mode (fp16 operands in HBM, one MFMA per MAC, fp32 accumulation, statistics and
-    ODE state) must deviate from the same fp32 golden by no more than 1.5x that, and its result must be about as far from the
-    autocast mel as that is from fp32 (two different roundings of one computation, not a different function)."""
+@pytest.mark.parametrize("terms,name", [(16, "fp16"), (17, "bf16")])
+def test_half_storage_mode_vs_reference_autocast_anchor(prod, synthetic, dev, monkeypatch, terms, name):
+    """The 16-bit storage modes (fp16 planes: terms 16; bfloat16 planes, the dtype BASELINE configs[2] names: terms 17) against
+    the reference-derived anchor on the SAME inputs (prod_synth: Tx=128, euler/10, seed-42 noise): the reference's synthesise
+    under torch.autocast(that dtype) -- what matcha/inference.py:238 runs -- deviates from its fp32 mel by err = (max, mean);
+    the HIP mode (16-bit operands in HBM, one MFMA per MAC, fp32 accumulation, statistics and ODE state) must deviate from the
+    same fp32 golden by no more than 1.5x that, and its result must be about as far from the autocast mel as that is from fp32
+    (two different roundings of one computation, not a different function)."""
     hp, sd, model = prod
     g = np.load(GOLDEN / "prod_synth.npz")
     a = np.load(GOLDEN / "prod_autocast.npz")
-    half = _half_model(hp, sd, dev, monkeypatch)
+    half = _half_model(hp, sd, dev, monkeypatch, terms)
     x, x_len, _ = synthetic.make_inputs(hp, 1, 128, seed=1234)
     z = synthetic.cpu_noise((1, 100, 640)).to(dev)
     half.decoder.solver = "euler"
     mel = half.synthesise(x.to(dev), x_len.to(dev), 10, speaker=0, z=z)["mel"].cpu()
     gold = _t(g["mel_euler10"])
     err_max, err_mean = maxabs(mel, gold), float((mel - gold).abs().mean())
-    ref_max, ref_mean = (float(v) for v in a["err_fp16"])
-    print(f"16-bit storage mode vs fp32 golden: max {err_max:.3e} mean {err_mean:.3e}; reference fp16 autocast: max {ref_max:.3e} mean {ref_mean:.3e}")
+    ref_max, ref_mean = (float(v) for v in a[f"err_{name}"])
+    print(f"{name} storage mode vs fp32 golden: max {err_max:.3e} mean {err_mean:.3e}; reference {name} autocast: max {ref_max:.3e} mean {ref_mean:.3e}")
     assert 1e-4 < err_max <= 1.5 * ref_max, (err_max, ref_max)
     assert err_mean <= 1.5 * ref_mean, (err_mean, ref_mean)
-    assert maxabs(mel, _t(a["mel_fp16"])) <= 2.5 * ref_max
+    assert maxabs(mel, _t(a[f"mel_{name}"])) <= 2.5 * ref_max
+    assert not bool(half.hip.range_flags().any().item())
 
 
 # ------------------------------------------------------------------------------------------------ range guard
