@@ -82,6 +82,7 @@ class FrameBudgetBatcher:
         self._cv = threading.Condition()
         self._stop = False
         self.batches_run = 0
+        self.busy_s = 0.0                   # wall time the worker spent inside batches (device work + its host side): a load gauge
         self._thread = threading.Thread(target=self._loop, name="mtts-batcher", daemon=True)
         self._thread.start()
 
@@ -130,8 +131,10 @@ class FrameBudgetBatcher:
                 batch = [self._waiting[i] for i in take]
                 for i in reversed(take):
                     del self._waiting[i]
+            t_run = time.monotonic()
             try:
                 results = self._run(batch)
+                self.busy_s += time.monotonic() - t_run
                 for r, res in zip(batch, results):
                     r.future.set_result(res)
             except BaseException as e:  # noqa: BLE001 - every waiter must be released

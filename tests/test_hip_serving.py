@@ -170,11 +170,11 @@ def test_config5_closed_loop_short_run(dev):
     hp, inference, model, batcher = ls.build(dev, with_vocoder=True, max_batch=8)
     try:
         batcher.submit([1] * 100, solver="midpoint", n_timesteps=4).result()
-        one = ls.run_level(batcher, inference, hp, users=1, seconds=3.0, seed=3, time_scale=0.05)
-        six = ls.run_level(batcher, inference, hp, users=6, seconds=4.0, seed=4, time_scale=0.02)
+        one = ls.run_level(batcher, inference, hp, 1, 2.0, 3, time_scale=0.05, min_requests=3, max_seconds=6.0, warm_seconds=1.0)
+        six = ls.run_level(batcher, inference, hp, 6, 3.0, 4, time_scale=0.02, min_requests=12, max_seconds=8.0, warm_seconds=1.0)
     finally:
         batcher.close()
     for r in (one, six):
         assert r["requests"] >= r["users"] and r["p50_latency_per_audio_s"] > 0 and r["p95_latency_s"] < 5.0
-    assert six["mean_batch"] > 1.0
+    assert six["mean_batch"] > 1.0 and 0.0 < six["worker_busy_fraction"] <= 1.0 and six["equivalent_users"] == 300
     assert model.hip.workspace_bytes_held() < 8 << 30          # grow-only scratch: bounded by the largest batch seen
