@@ -74,6 +74,14 @@ void mtts_destroy(mtts_ctx* ctx);
  * Replaces nn.Module.load_state_dict (reference inference.py:186-197). */
 int mtts_set_tensor(mtts_ctx* ctx, const char* key, const float* h_data, int64_t numel);
 
+/* Threading: a context carries per-call state (the call's range-flag pointer, frame limits, the profiler's records): one thread
+ * drives a context at a time -- use one context per serving worker / stream.  The path's entry points (mtts_text_encoder_forward,
+ * mtts_decoder_forward, mtts_cfm_solve*) enforce it: a call that finds the context held by another thread returns -1 ("in use
+ * by another thread") instead of interleaving.  Only mtts_last_error is thread-local. */
+
+/* (test hook: holds the context as a path entry point does for `ms` milliseconds; a concurrent entry-point call fails) */
+int mtts_debug_hold(mtts_ctx* ctx, int ms);
+
 /* Packed-image cache ("pre-packed MFMA weight layouts cached beside the converted checkpoint").
  * mtts_weights_signature: a string naming everything the image layout depends on (ABI and image revision, architecture,
  * arithmetic, layout switches); mtts_export_weights copies the packed image (mtts_weights_bytes) to host memory;
@@ -309,6 +317,9 @@ int mtts_prof_reset(mtts_ctx* ctx);
 int mtts_prof_read(mtts_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops, double* bytes);
 /* The same records one by one, in launch order: h_out[4 i ..] = (class, ms, flops, bytes); returns the count (<= max_records). */
 int64_t mtts_prof_records(mtts_ctx* ctx, double* h_out, int64_t max_records);
+/* the kernel instantiation of each of those records, in the same order, '\n'-separated ("-" = untagged): the names rocprofv3
+ * prints, e.g. "gemm_p16_kernel<64, false, 3, 0, true, false, 2>"; returns the record count */
+int64_t mtts_prof_tags(mtts_ctx* ctx, char* out, int64_t max_bytes);
 
 #ifdef __cplusplus
 }

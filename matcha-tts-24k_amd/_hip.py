@@ -128,6 +128,7 @@ def load() -> C.CDLL:
         "mtts_set_tensor": (i32, [vp, C.c_char_p, vp, i64]),
         "mtts_weights_bytes": (i64, [vp]),
         "mtts_upload_weights": (i32, [vp, vp, i64]),
+        "mtts_debug_hold": (i32, [vp, i32]),
         "mtts_weights_signature": (i32, [vp, C.c_char_p, i64]),
         "mtts_export_weights": (i32, [vp, vp, i64, C.POINTER(i32)]),
         "mtts_import_weights": (i32, [vp, vp, i64, i32]),
@@ -174,6 +175,7 @@ def load() -> C.CDLL:
         "mtts_prof_enable": (i32, [vp, i32]),
         "mtts_prof_reset": (i32, [vp]),
         "mtts_prof_records": (i64, [vp, C.POINTER(C.c_double), i64]),
+        "mtts_prof_tags": (i64, [vp, C.c_char_p, i64]),
         "mtts_prof_read": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -510,6 +512,14 @@ class HipModel:
         if n < 0:
             check(-1)
         return [(int(buf[4 * i]), buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(n)]
+
+    def prof_tags(self, max_bytes: int = 1 << 24):
+        """Kernel instantiation name of each record of ``prof_records`` ("-" where the launcher does not tag)."""
+        buf = C.create_string_buffer(max_bytes)
+        n = self.lib.mtts_prof_tags(self.ctx, buf, max_bytes)
+        if n < 0:
+            check(-1)
+        return buf.value.decode().split("\n")[:n]
 
 
 # ---------------------------------------------------------------------- single kernels (used by the parity tests)

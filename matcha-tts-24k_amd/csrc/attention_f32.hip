@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include <cstdlib>
+#include <string>
 
 namespace mtts {
 
@@ -60,18 +61,26 @@ __device__ __forceinline__ f32x16 att_mfma(f16x8 a, f16x8 b, f32x16 c) {
     if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_a, a), __builtin_bit_cast(bf16x8_a, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-template <int NW, bool P16, bool ONE = false, bool HALF = false, bool BF = false>
-__global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArgs p) {
+// KR: key rows held in LDS.  AT_K (the default): one 64-key tile at a time, the next one prefetched into registers, two
+// barriers per tile.  KR = 192 ("whole"): short sequences (the half-length level of the estimator: 161 keys) -- one workgroup
+// per (utterance, head) with a wave per 32 queries stages ALL keys and values once, in one batch of loads and behind one
+// barrier, and the tile loop then runs without fetches or barriers.  At 161 keys the tiled form is mostly prologue and exposed
+// round trips (16 us per launch for 1.3 GFLOP: round-2 verdict, "attention_f32_kernel<2, ...> MFMA busy 0.09"), and its three
+// query blocks per head each re-stage the same keys.
+template <int NW, bool P16, bool ONE = false, bool HALF = false, bool BF = false, int KR = AT_K>
+__global__ __launch_bounds__(64 * NW, KR > AT_K ? 1 : 2) void attention_f32_kernel(const AttnArgs p) {
     static_assert(!HALF || (P16 && ONE), "H16 I/O runs the single-product loop");
     static_assert(!BF || HALF, "bfloat16 planes exist in the 16-bit storage mode only");
+    constexpr bool WHOLE = KR > AT_K;
     constexpr int NT = 64 * NW;                   // threads
     constexpr int SROWS = NT / 4;                 // key rows staged per pass (4 threads x float4 x 4 = one 64-float row)
-    constexpr int SP = AT_K / SROWS;              // passes over the 64-row tile
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[2 * AT_K * AT_KS];   // planes h | l
+    constexpr int SP = KR / SROWS;                // passes over the rows held
+    static_assert(SP >= 1 && SP * SROWS == KR && (!WHOLE || NW * AT_QW >= KR), "staging passes cover the rows held");
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[2 * KR * AT_KS];   // planes h | l
     // V planes h | l, row-major and split by d half: [plane][d >> 5][key][d & 31] (64-byte rows, no padding).  P.V needs V^T
     // fragments; ds_read_b64_tr_b16 transposes 4 keys x 16 d blocks on the way out of LDS, so staging is plain row stores.
-    __shared__ __attribute__((aligned(16))) _Float16 Vs[2 * 2 * AT_K * 32];
-    __shared__ __attribute__((aligned(16))) float Bs[AT_K];
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[2 * 2 * KR * 32];
+    __shared__ __attribute__((aligned(16))) float Bs[KR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, h = lane >> 5;
@@ -181,16 +190,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 for (int c = 0; c < 2; ++c) {      // chunk (tid&3) + 4c = dims 8 (tid&3) + 32 c ..+7 of the one plane
                     const int d = 32 * c + 8 * (tid & 3);
                     *reinterpret_cast<f32x4*>(Ks + r * AT_KS + d) = r_in[sp] ? rk[sp][c] : zero;
-                    *reinterpret_cast<f32x4*>(Vs + (c * AT_K + r) * 32 + 8 * (tid & 3)) = r_in[sp] ? rv[sp][c] : zero;
+                    *reinterpret_cast<f32x4*>(Vs + (c * KR + r) * 32 + 8 * (tid & 3)) = r_in[sp] ? rv[sp][c] : zero;
                 }
             } else if constexpr (P16) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {      // chunk (tid&3) + 4c: plane c&1 (head / residual), dims 32 (c>>1) + 8 (tid&3) ..+7
                     const int plane = c & 1, d = 32 * (c >> 1) + 8 * (tid & 3);
                     const f32x4 kraw = r_in[sp] ? rk[sp][c] : zero;
-                    *reinterpret_cast<f32x4*>(Ks + plane * AT_K * AT_KS + r * AT_KS + d) = kraw;
+                    *reinterpret_cast<f32x4*>(Ks + plane * KR * AT_KS + r * AT_KS + d) = kraw;
                     const f32x4 vraw = r_in[sp] ? rv[sp][c] : zero;
-                    *reinterpret_cast<f32x4*>(Vs + ((plane * 2 + (c >> 1)) * AT_K + r) * 32 + 8 * (tid & 3)) = vraw;
+                    *reinterpret_cast<f32x4*>(Vs + ((plane * 2 + (c >> 1)) * KR + r) * 32 + 8 * (tid & 3)) = vraw;
                 }
             } else
 #pragma unroll
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     kl[e] = (_Float16)(kv[e] - (float)a);
                 }
                 *reinterpret_cast<f16x4*>(Ks + r * AT_KS + sd + 16 * c) = kh;
-                *reinterpret_cast<f16x4*>(Ks + AT_K * AT_KS + r * AT_KS + sd + 16 * c) = kl;
+                *reinterpret_cast<f16x4*>(Ks + KR * AT_KS + r * AT_KS + sd + 16 * c) = kl;
                 const f32x4 vv = ok ? rv[sp][c] : zero;
                 f16x4 vh4, vl4;
 #pragma unroll
@@ -215,8 +224,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                     vl4[e] = (_Float16)(vv[e] - (float)a);
                 }
                 const int dcol = sd + 16 * c;              // 4 consecutive d of key r
-                *reinterpret_cast<f16x4*>(Vs + ((dcol >> 5) * AT_K + r) * 32 + (dcol & 31)) = vh4;
-                *reinterpret_cast<f16x4*>(Vs + ((2 + (dcol >> 5)) * AT_K + r) * 32 + (dcol & 31)) = vl4;
+                *reinterpret_cast<f16x4*>(Vs + ((dcol >> 5) * KR + r) * 32 + (dcol & 31)) = vh4;
+                *reinterpret_cast<f16x4*>(Vs + ((2 + (dcol >> 5)) * KR + r) * 32 + (dcol & 31)) = vl4;
             }
             if ((tid & 3) == 0) {
                 float bv = ninf;
@@ -228,11 +237,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
 
     const int ntiles = (Tb + AT_K - 1) / AT_K;
     fetch(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt) __syncthreads();          // everyone finished reading the previous tile
+    if constexpr (WHOLE) {                // every key row of the utterance, once
         stage();
         __syncthreads();
-        if (kt + 1 < ntiles) fetch((kt + 1) * AT_K);
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int kbase = WHOLE ? kt * AT_K : 0;      // first row of this tile in the LDS arrays
+        if constexpr (!WHOLE) {
+            if (kt) __syncthreads();      // everyone finished reading the previous tile
+            stage();
+            __syncthreads();
+            if (kt + 1 < ntiles) fetch((kt + 1) * AT_K);
+        }
 
         // ---- S^T = K . Q^T for 2 sub-tiles of 32 keys (A = K fragment: lane (key, h) holds K[key][16kb + 8h + j]).
         // (Skipping the second sub-tile of a last tile with <= 32 keys -- T = 322 leaves two -- measured SLOWER, 3.20 vs 3.02 ms of
@@ -242,11 +258,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-            const _Float16* kp = Ks + (32 * t + lq) * AT_KS + 8 * h;
+            const _Float16* kp = Ks + (kbase + 32 * t + lq) * AT_KS + 8 * h;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(kp + 16 * kb);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + AT_K * AT_KS + 16 * kb);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + KR * AT_KS + 16 * kb);
                 if constexpr (!ONE) {
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + 32 * t + 8 * g4 + 4 * h);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + kbase + 32 * t + 8 * g4 + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = fmaf(s[t][4 * g4 + e], scale2, bb[e]);     // log2 domain: one FMA per score
@@ -315,10 +331,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const AttnArg
                 for (int dt = 0; dt < 2; ++dt) {
                     // transposed reads: the 16-lane group g = lane>>4 takes the block keys k0..k0+3 x d 32 dt + 16 (g&1) ..+15;
                     // lane 4q+p of the group addresses key k0+q, columns 4p..4p+3, and receives column lane&15 of the 4 keys
-                    const _Float16* vp = Vs + ((dt * AT_K) + k0 + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                    const _Float16* vp = Vs + ((dt * KR) + kbase + k0 + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
                     f16x8 vh, vl;
                     const f16x4 h0 = tr_read4(vp), h1 = tr_read4(vp + 8 * 32);
-                    const f16x4 l0 = tr_read4(vp + 2 * AT_K * 32), l1 = tr_read4(vp + 2 * AT_K * 32 + 8 * 32);
+                    const f16x4 l0 = tr_read4(vp + 2 * KR * 32), l1 = tr_read4(vp + 2 * KR * 32 + 8 * 32);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
                     if constexpr (!ONE) {
@@ -399,6 +415,27 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     // two workgroups per CU: half as many workgroups re-stage each head's keys and values)
     const bool same_rows = b128 * 128 == b64 * 64 && blocks128 >= 512;
     const bool use128 = env_nw == 4 || (env_nw == 0 && ((blocks128 >= 768 && waste128 < 0.1) || same_rows));
+    {
+        static thread_local std::string tag;
+        const bool one = a.half16 || (p16 && a.fast16);
+        tag = std::string("attention_f32_kernel<") + (use128 ? "4" : "2") + ", " + tf(p16) + ", " + tf(one) + ", " + tf(a.half16) + ", " + tf(a.half16 && a.bf16) + ">";
+        g_kernel_tag = tag.c_str();
+    }
+    // short sequences (65..192 keys: the estimator's half-length level) on P16 / H16 images: one workgroup per (utterance, head),
+    // all keys staged once (KR = 192); MTTS_ATTN_WHOLE=0 keeps the tiled kernel (A/B runs)
+    static const bool whole_on = [] { const char* e = getenv("MTTS_ATTN_WHOLE"); return !(e && e[0] == '0'); }();
+    if (p16 && whole_on && env_nw == 0 && a.T > 64 && a.T <= 192) {
+        static thread_local std::string wtag;
+        const bool one = a.half16 || a.fast16;
+        wtag = std::string("attention_f32_kernel<6, true, ") + tf(one) + ", " + tf(a.half16) + ", " + tf(a.half16 && a.bf16) + ", 192>";
+        g_kernel_tag = wtag.c_str();
+        const dim3 grid(a.H * a.B), block(384);
+        if (a.half16 && a.bf16) hipLaunchKernelGGL((attention_f32_kernel<6, true, true, true, true, 192>), grid, block, 0, s, a);
+        else if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<6, true, true, true, false, 192>), grid, block, 0, s, a);
+        else if (a.fast16) hipLaunchKernelGGL((attention_f32_kernel<6, true, true, false, false, 192>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attention_f32_kernel<6, true, false, false, false, 192>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (use128) {
         if (a.half16 && a.bf16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);
         else if (a.half16) hipLaunchKernelGGL((attention_f32_kernel<4, true, true, true>), dim3(b128 * a.H * a.B), dim3(256), 0, s, a);

@@ -30,6 +30,7 @@
 //      block (3/16 of the fp32-MFMA cycles).  Measured error vs fp64 equals the fp32 chain's.  Inputs beyond the fp16
 //      range (|x| > 65504) saturate instead of overflowing.
 #include "kernels.h"
+#include <string>
 #include "device_utils.h"
 #include "gemm_epilogue.h"
 
@@ -37,6 +38,8 @@
 #include <cstring>
 
 namespace mtts {
+
+thread_local const char* g_kernel_tag = nullptr;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -433,6 +436,8 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     }
     const int M = a.B * a.T_out;
     const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    static const std::string tag = "gemm_f32_kernel<" + std::to_string(BM) + ", " + tf(A_MASK) + ", " + tf(A_NORM) + ", " + std::to_string(TERMS) + ">";
+    g_kernel_tag = tag.c_str();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }

@@ -27,6 +27,7 @@
 #endif
 #include "gemm_epilogue.h"
 #include <cstdlib>
+#include <string>
 
 
 namespace mtts {
@@ -536,6 +537,9 @@ static hipError_t launch_p16_shape(const GemmArgs& a, hipStream_t s) {
     }
     const int M = a.B * a.T_out;
     const int grid = ((M + BM - 1) / BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
+    static const std::string tag = "gemm_p16_kernel<" + std::to_string(BM) + ", " + tf(LN) + ", " + std::to_string(NST) + ", " + std::to_string(MODE) +
+                                   ", " + tf(M16) + ", " + tf(GN) + ", " + std::to_string(KS) + ">";
+    g_kernel_tag = tag.c_str();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * KS), lds_bytes, s, a);
     return hipGetLastError();
 }

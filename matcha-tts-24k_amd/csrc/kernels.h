@@ -14,6 +14,12 @@ constexpr int MAX_TAPS = 7;
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Name of the kernel instantiation the last launcher call on this thread chose, spelled as rocprofv3 prints it (e.g.
+// "gemm_p16_kernel<64, false, 3, 0, true, false, 2>"): the per-launch event pass (mtts_prof_*) stores it with each record, so a
+// per-instantiation table can join measured FLOP/s with the profiler's counters (tools/kernel_table.py).  Null = untagged.
+extern thread_local const char* g_kernel_tag;
+static inline const char* tf(bool b) { return b ? "true" : "false"; }
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SNAKE = 3, ACT_GELU = 4 };
 
 // C[M,N] = epi( pro(A)[M,K] . W[N,K]^T )   -- see gemm_f32.hip for the tiling.

@@ -1,6 +1,7 @@
 // Host-side model of the path: packed weights, workspace planning and the launch sequences of
 // TextEncoder.forward, Decoder.forward and BASECFM.solve (reference files cited at each function in model.hip).
 #pragma once
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -75,7 +76,7 @@ struct VocosW {
     std::vector<Panel> pw1, pw2;
 };
 
-struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; };
+struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; const char* tag; };
 
 }  // namespace mtts
 
@@ -102,6 +103,9 @@ struct mtts_ctx {
                                   // measured at width 384 -- 10304 rows: 138 vs ~160 us per block; 5152 rows: 100 vs ~92 us (profiles/r03_chain_*)
     mtts::DecW dec;
     mtts::EncW enc;
+    // one thread at a time: the path's entry points hold this while they enqueue (per-call state above: cur_flag, half_now,
+    // d_tlen, prof); a second thread's call fails instead of interleaving its launches with another call's flag pointer
+    std::atomic<bool> in_use{false};
     // profiling
     bool prof_on = false;
     std::vector<mtts::ProfRec> prof;

@@ -16,8 +16,10 @@
 //   * the weights never touch LDS.  Each wave owns C/8 output channels (CH/8 hidden channels in FF1) and reads "its" panel rows as
 //     a fragment stream: 1 KiB fragments (16 rows x 32 k of one fp16 plane, lane-major) in consumption order, one
 //     global_load_dwordx4 per lane each, through a register ring of R fragments (~12 KiB per wave in flight: what a ~2k-cycle
-//     L2 round trip needs at the CU's ingest rate).  Plain loads only: the compiler's own vmcnt bookkeeping holds, no LDS-DMA,
-//     no hand-counted waits (round-2 advisor finding on gemm_p16.hip's ring);
+//     L2 round trip needs at the CU's ingest rate).  The loads are inline asm with hand-written waits (see CH_LOAD below: hipcc
+//     sinks plain loads next to their use), and every k-loop ENDS with a drain of the ring: no asm load is in flight while
+//     compiler-scheduled code (an epilogue, LayerNorm moments) runs, because the compiler may copy such a register before the
+//     load has landed;
 //   * products are computed TRANSPOSED, D^T[channel][row] = W . X^T (A = weight fragment, B = activation fragment): a lane then
 //     holds 4 consecutive channels of one row, so every LDS / global store of an epilogue is 8 bytes of one image line;
 //   * LayerNorm statistics are taken from the LDS tile (one wave per row, two passes), applied after the product as
@@ -26,6 +28,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include <cstring>
+#include <string>
 #include <cmath>
 
 namespace mtts {
@@ -178,6 +181,18 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     const bool has_out = p.inner > 0, has_qkv = p.b_qkv != nullptr;
     const unsigned int lane16 = lane * 16;                          // per-lane byte offset of the stream loads
     CH_STAMP(0);
+#ifdef MTTS_CHAIN_DUMP
+    // diagnostic: copies of the LDS regions at the phase boundaries, per workgroup [x0 | ct | x1 | srow | h0 | x2] (p.kstamp = base)
+    constexpr int DUMP_WG = 3 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4 + K::HT_BYTES;
+    auto dump = [&](int sect_off, const char* src, int bytes) {
+        if (!p.kstamp) return;
+        char* dst = reinterpret_cast<char*>(p.kstamp) + (size_t)blockIdx.x * DUMP_WG + sect_off;
+        for (int o = tid * 16; o < bytes; o += 64 * CHAIN_NW * 16) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
+    };
+#define CH_DUMP(off, src, bytes) dump(off, src, bytes)
+#else
+#define CH_DUMP(off, src, bytes) do { } while (0)
+#endif
 
     // ---- the wave's weight stream through a register ring: fragment f of the current position sits in ring[f % R].
     // wpos: (uniform) address of the fragment that is the current position.
@@ -258,15 +273,9 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     // one k-step of a C-wide product: wait for its NT weight tiles (ring slots fb ..), multiply with the activation fragments of
     // k-group kg of `base`, then request the fragments R further on into the same slots.  The wait, by what else this file has
     // requested since (mode): 0 nothing -- the R - FW younger fragments of the ring; 1 the out-projection's attention rows (see
-    // phase 0: FW + 1); 2 the 2 NT MT image stores of the previous q|k|v pass's epilogue, when this workgroup issued exactly that
-    // many (`stores_exact`: all rows valid, all tiles valid) -- they are younger than fragments requested before that epilogue,
-    // and not counting them would make the first steps of a pass wait for the stores' round trip.
-    // (fb, frag, mode: constants once the caller's loop is unrolled.)
-    bool stores_exact = false;
+    // phase 0: FW + 1).  (fb, frag, mode: constants once the caller's loop is unrolled.)
     auto step_wide = [&](int fb, const char* base, int kg, int frag, int mode) __attribute__((always_inline)) {
-        if (mode == 0) CH_WAIT(R - FW);
-        else if (mode == 1) CH_WAIT(FW + 1);
-        else if (stores_exact) CH_WAIT(R - FW + 2 * NT * MT);
+        if (mode == 1) CH_WAIT(FW + 1);
         else CH_WAIT(R - FW);
 #pragma unroll
         for (int f = 0; f < FW; ++f) CH_TIE(ring[(fb + f) % R]);
@@ -283,6 +292,17 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) refill(fb + 2 * t, frag + 2 * t);
+    };
+    // End of every k-loop: nothing this file requested may still be in flight when compiler-scheduled code follows.  The compiler
+    // treats an asm output as available at once, so wherever it splits the live range of a ring register (it does around the
+    // register-hungry epilogues) it copies the register BEFORE the load has landed -- the copy then holds the previous fragment.
+    // That was the round-3 determinism failure: right results whenever the weights came out of the L2 fast enough, wrong ones for
+    // a whole launch when they did not (first launch after other kernels had emptied the L2s).  tests/test_isa_guard.py walks the
+    // control-flow graph of the built kernel and fails on any instruction that touches a register with its load outstanding.
+    auto ring_drain = [&]() __attribute__((always_inline)) {
+        CH_WAIT(0);
+#pragma unroll
+        for (int i = 0; i < R; ++i) CH_TIE(ring[i]);
     };
     float rmax = 0.f;
     // acc (+ bias + the residual rows in XT) -> XT, in place: this lane's channels 16 (wave NT + t) + 4 q .. + 3 of rows 16 i + c
@@ -348,6 +368,8 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         zero_acc();
         __syncthreads();
         CH_STAMP(1);
+        CH_DUMP(0, XT, K::XT_BYTES);
+        CH_DUMP(K::XT_BYTES, reinterpret_cast<const char*>(CT), K::CT_FLOATS * 4);
         for (int s0 = 0; s0 < nk0; s0 += PER0) {
 #pragma unroll
             for (int u = 0; u < PER0; ++u) {
@@ -364,15 +386,19 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             }
             wpos += R * 1024;
         }
+        ring_drain();
+        CH_TIE(areg[0]); CH_TIE(areg[1]);
         CH_STAMP(2);
         rows_to_xt(CT + 16 * C);
         __syncthreads();
+        CH_DUMP(K::XT_BYTES + K::CT_FLOATS * 4, XT, K::XT_BYTES);
     } else {
         __syncthreads();                                  // the x tile is in LDS
     }
     ln_stats();
     __syncthreads();
     CH_STAMP(3);
+    CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4, reinterpret_cast<const char*>(srow), 2 * QB * 4);
 
     // ================================================================ phase 1: FeedForward (reference transformer.py:278-301,104-120)
     zero_acc();
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) refill(fb + 2 * t, s * F1S + 2 * t);
             }
+            ring_drain();
             if (j < 2) CH_STAMP(4 + 3 * j);
             // ---- LayerNorm after the product, SnakeBeta, split -> hidden chunk image in HT
             float nmr[MT], rstd[MT];                      // this lane's rows: -mean rstd, rstd
@@ -432,9 +459,11 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             }
             __syncthreads();
             if (j < 2) CH_STAMP(5 + 3 * j);
+            if (j == 0) CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4, HT, K::HT_BYTES);
             // ---- FF2: out^T += W2[:, chunk] . hidden chunk^T
 #pragma unroll
             for (int s = 0; s < KG2; ++s) step_wide((F1 + s * FW) % R, HT, s, F1 + s * FW, 0);
+            ring_drain();
             wpos += (F1 + KG2 * FW) * 1024;
             __syncthreads();                              // the hidden chunk may be overwritten
             if (j < 2) CH_STAMP(6 + 3 * j);
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     CH_STAMP(10);
     rows_to_xt(CT + 17 * C);
     __syncthreads();
+    CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4 + K::HT_BYTES, XT, K::XT_BYTES);
 
     // ---- the block's output rows: LDS image -> global image, whole 16-byte chunks, coalesced
     {
@@ -467,14 +497,12 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         __syncthreads();
         const int ntiles = p.n_qkv >> 4;
         const int passes = (ntiles + CHAIN_NW * NT - 1) / (CHAIN_NW * NT);
-        static_assert(R - FW + 2 * NT * MT < 64, "vmcnt is a 6-bit counter");
-        const bool all_stores = m0 + QB <= M && ntiles % (CHAIN_NW * NT) == 0;      // (uniform) every store of an epilogue is issued
+        const bool all_stores = m0 + QB <= M;             // (uniform) no row of the tile is past the end
         for (int ps = 0; ps < passes; ++ps) {
             zero_acc();
-            stores_exact = all_stores && ps > 0;
-            // fragments with index < R (relative to the pass) were requested during the previous pass's k-loop, before its stores
 #pragma unroll
-            for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, (s * FW + FW - 1 < R) ? 2 : 0);
+            for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, 0);
+            ring_drain();
             wpos += KG * FW * 1024;
             CH_STAMP(13 + (ps < 2 ? ps : 2));
             float nmr[MT], rstd[MT];
@@ -509,6 +537,32 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     }
     raise_range_flag(p.range_flag, rmax > 65504.f);
     CH_STAMP(12);
+#ifdef MTTS_CHAIN_PROBE
+    // diagnostic: per workgroup [HW_ID, XCC_ID, hash of the constants in LDS, hash of the kernel arguments as this wave holds them,
+    // hash of the row statistics, -, -, -] (p.kstamp = base, zeroed by the host)
+    if (p.kstamp) {
+        unsigned int* rec = reinterpret_cast<unsigned int*>(p.kstamp) + (size_t)blockIdx.x * 8;
+        unsigned int hc = 0, hs = 0;
+        for (int i = tid; i < K::CT_FLOATS; i += 64 * CHAIN_NW) hc ^= (__float_as_uint(CT[i]) + 0x9e3779b9u * (unsigned)i) * 2654435761u;
+        for (int i = tid; i < 2 * QB; i += 64 * CHAIN_NW) hs ^= (__float_as_uint(srow[i]) + 0x9e3779b9u * (unsigned)i) * 2654435761u;
+        atomicXor(rec + 2, hc);
+        atomicXor(rec + 4, hs);
+        if (lane == 0) {
+            const unsigned long long ptrs[10] = {(unsigned long long)p.att16, (unsigned long long)p.x16, (unsigned long long)p.wstream, (unsigned long long)p.b_out,
+                (unsigned long long)p.b1, (unsigned long long)p.wsum1, (unsigned long long)p.p0, (unsigned long long)p.p1, (unsigned long long)p.b2,
+                (unsigned long long)p.x_out_mask};
+            unsigned long long h = (unsigned long long)p.M * 1315423911ull + (unsigned long long)p.stream_frags;
+            for (int i = 0; i < 10; ++i) h = (h ^ ptrs[i]) * 1099511628211ull;
+            atomicXor(rec + 3, (unsigned int)(h ^ (h >> 32)) * (1u + 0u * wave));      // all 8 waves: equal hashes cancel pairwise -> 0 when they agree
+            atomicAdd(rec + 5, (unsigned int)(h ^ (h >> 32)) == 0u ? 0u : 1u);
+            if (wave == 0) {
+                rec[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_ID
+                rec[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // XCC_ID
+                rec[6] = (unsigned int)(h ^ (h >> 32));
+            }
+        }
+    }
+#endif
 }
 
 template <int C, int QB, int CH>
@@ -522,6 +576,8 @@ static hipError_t launch_chain_shape(const ChainArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured = true;
     }
+    static const std::string tag = "tblock_chain_kernel<" + std::to_string(C) + ", " + std::to_string(QB) + ", " + std::to_string(CH) + ">";
+    g_kernel_tag = tag.c_str();
     hipLaunchKernelGGL(kern, dim3((a.M + QB - 1) / QB), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
     return hipGetLastError();
 }

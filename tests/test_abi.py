@@ -146,3 +146,23 @@ def test_chain_fragment_stream_layout(lib, C, inner, ch, n_qkv):
     for name, ref in (("out", w_out), ("w1", w1), ("w2", w2), ("qkv", w_qkv)):
         if ref is not None and ref.size:
             assert np.abs(got[name] - ref).max() <= 2.0 ** -21 * np.abs(ref).max(), name
+
+
+def test_context_refuses_concurrent_use(lib, hparams):
+    """A context is single-threaded (per-call state: range-flag pointer, frame limits, profiler records).  While one thread is
+    inside an entry point -- stood in for by the mtts_debug_hold test hook, no GPU needed -- another thread's call returns an
+    error naming the cause instead of interleaving its launches; afterwards the context works again."""
+    import threading
+    import time
+    hip = sub("_hip")
+    h = hip.HipModel(hparams.tiny())
+    t = threading.Thread(target=lambda: lib.mtts_debug_hold(h.ctx, 400))
+    t.start()
+    time.sleep(0.1)
+    rc = lib.mtts_text_encoder_forward(h.ctx, None, None, None, None, 1, 4, None, None, None, None, 0, None)
+    msg = lib.mtts_last_error()
+    t.join()
+    assert rc == -1 and b"in use by another thread" in msg
+    assert lib.mtts_debug_hold(h.ctx, 1) == 0                       # released
+    rc = lib.mtts_text_encoder_forward(h.ctx, None, None, None, None, 1, 4, None, None, None, None, 0, None)
+    assert rc == -1 and b"weights not uploaded" in lib.mtts_last_error()      # the ordinary check, not the guard

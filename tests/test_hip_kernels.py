@@ -256,9 +256,10 @@ def test_attention(hip, oracle, B, T, H, D, mode):
     close(out, ref, 5e-6)
 
 
-@pytest.mark.parametrize("B,T,H,mode", [(2, 320, 6, 0), (1, 640, 2, 0), (3, 130, 2, 1), (32, 640, 6, 0)])
+@pytest.mark.parametrize("B,T,H,mode", [(2, 320, 6, 0), (1, 640, 2, 0), (3, 130, 2, 1), (32, 640, 6, 0), (4, 161, 6, 0), (2, 192, 3, 0), (3, 65, 2, 0)])
 def test_attention_p16_io(hip, oracle, B, T, H, mode):
-    """Same kernel with q|k|v read from a P16 image and the output written as one (the decoder's transformer blocks)."""
+    """Same kernel with q|k|v read from a P16 image and the output written as one (the decoder's transformer blocks).  T in
+    65..192 runs the whole-sequence form (one workgroup per utterance and head, every key staged once): the half-length level."""
     D = 64
     qkv = rnd(B * T, 3 * H * D, seed=22)
     lens = torch.tensor([T - 3 * i for i in range(B)])

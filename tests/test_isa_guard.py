@@ -1,6 +1,10 @@
 """Build-time guard of the instruction streams the kernels' hand-counted `s_waitcnt vmcnt(N)` depend on (CPU only: the gfx950 code
 objects of the in-tree build are disassembled with llvm-objdump, nothing runs).
 
+The check that matters most is `test_chain_kernel_never_touches_a_register_with_its_load_outstanding`: the round-3 determinism
+failure (a whole chain launch a few per cent off, once in a few hundred launches) was hipcc copying ring registers between two
+phases of tblock_chain_kernel BEFORE the inline-asm loads into them had landed.
+
 Two kernels count vector-memory operations by hand:
   * gemm_p16_kernel's LDS-DMA ring (csrc/gemm_p16.hip): tile D-1 .. D requests with (D-1) * PER_TILE (+ the residual prefetch) loads
     in flight across a raw s_barrier;
@@ -87,12 +91,28 @@ def p16_isa(tmp_path_factory):
     return disassemble("gemm_p16", tmp_path_factory)
 
 
+def test_chain_kernel_never_touches_a_register_with_its_load_outstanding(chain_isa):
+    """tblock_chain_kernel<C, QB, CH>, every instantiation, every path of its control-flow graph: between a vector-memory load and
+    the `s_waitcnt vmcnt(N)` that retires it, no instruction reads or writes the load's destination (tools/isa_pending.py).  The
+    hardware has no interlock there and the compiler does not know the inline-asm loads are asynchronous: a live-range split, a
+    spill or a register reuse inside that window compiles, passes every test on a warm L2 and reads the previous fragment on a
+    cold one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_pending", ROOT / "tools" / "isa_pending.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    names = [n for n in chain_isa if "tblock_chain_kernel" in n]
+    assert len(names) >= 6
+    for name in names:
+        bad = mod.pending_violations(chain_isa[name])
+        assert not bad, (name, [(hex(o), m, ops) for o, m, ops, _ in bad[:6]])
+
+
 def test_chain_kernel_rings_are_not_spilled_and_waits_are_the_written_ones(chain_isa):
     """tblock_chain_kernel<C, QB, CH>: the fragment ring lives in registers that inline-asm loads fill; the compiler treats an asm
     output as available at once, so a spill (or any compiler-made copy) of a ring register ahead of its wait would store
     garbage.  Inside every loop with matrix instructions: no scratch traffic, no vector-memory loads except the ring's
-    global_load_dwordx4, only the hand-written vmcnt constants; and the q|k|v pass issues exactly the 2 NT MT image stores its
-    counted waits assume."""
+    global_load_dwordx4, only the hand-written vmcnt constants (0 = the drain that ends every k-loop)."""
     names = [n for n in chain_isa if "tblock_chain_kernel" in n]
     assert len(names) >= 6
     for name in names:
@@ -109,7 +129,7 @@ def test_chain_kernel_rings_are_not_spilled_and_waits_are_the_written_ones(chain
             assert not any(x[1].startswith("scratch_") for x in insns[mf[0]:mf[-1]]), (name, "scratch traffic among the k-loops")
             continue
         assert len(hot) >= 3, (name, hot)                     # out-projection, hidden chunks, q|k|v passes
-        allowed = {R - FW, R - F1S, FW + 1, R - FW + 2 * NT * MT}
+        allowed = {0, R - FW, R - F1S, FW + 1}                 # 0: the drain that ends every k-loop
         seen_chunk = seen_qkv = False
         for a, b in hot:
             body = insns[a:b + 1]
@@ -130,7 +150,6 @@ def test_chain_kernel_rings_are_not_spilled_and_waits_are_the_written_ones(chain
             elif n_mfma == 3 * MT * KG * NT and ops.get("global_store_dwordx2", 0):   # a q|k|v pass
                 seen_qkv = True
                 assert n_load == KG * FW, (name, n_load)
-                assert ops["global_store_dwordx2"] == 2 * NT * MT, (name, ops["global_store_dwordx2"])
         assert seen_chunk and seen_qkv, name
 
 

@@ -20,17 +20,26 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--splits", default="1,2,4")
-    ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--threads", type=int, default=1, help="1: one host thread AND one model (= one mtts_ctx) per stream; 0: one thread issues all streams")
     args = ap.parse_args()
     hparams = importlib.import_module(PKG + ".hparams")
     synthetic = importlib.import_module(PKG + ".synthetic")
     inference = importlib.import_module(PKG + ".inference")
     dev = torch.device("cuda")
     hp = hparams.prod_v20(n_spks=1)
-    model = inference.MatchaTTSInfer(**hp.as_reference_kwargs())
-    model.load_state_dict(synthetic.make_state_dict(hp, seed=7), strict=True)
-    model = model.to(dev).eval()
-    model.decoder.solver = "euler"
+    sd = synthetic.make_state_dict(hp, seed=7)
+
+    def make_model():
+        m = inference.MatchaTTSInfer(**hp.as_reference_kwargs())
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).eval()
+        m.decoder.solver = "euler"
+        return m
+
+    # a context is single-threaded (include/mtts.h "Threading"; the entry points refuse concurrent use): with host threads every
+    # stream gets a model of its own
+    n_models = max(int(v) for v in args.splits.split(",")) if args.threads else 1
+    models = [make_model() for _ in range(n_models)]
     x, x_len, _ = synthetic.make_inputs(hp, args.batch, 128, seed=1234)
     x, x_len = x.to(dev), x_len.to(dev)
     for S in [int(v) for v in args.splits.split(",")]:
@@ -39,7 +48,7 @@ def main():
 
         def part(i):
             with torch.cuda.stream(streams[i]):
-                model.synthesise(x[i * per:(i + 1) * per], x_len[i * per:(i + 1) * per], 10, speaker=0)
+                models[i if args.threads else 0].synthesise(x[i * per:(i + 1) * per], x_len[i * per:(i + 1) * per], 10, speaker=0)
 
         def step():
             if args.threads and S > 1:
