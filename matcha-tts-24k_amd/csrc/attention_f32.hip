@@ -418,7 +418,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     {
         static thread_local std::string tag;
         const bool one = a.half16 || (p16 && a.fast16);
-        tag = std::string("attention_f32_kernel<") + (use128 ? "4" : "2") + ", " + tf(p16) + ", " + tf(one) + ", " + tf(a.half16) + ", " + tf(a.half16 && a.bf16) + ">";
+        tag = std::string("attention_f32_kernel<") + (use128 ? "4" : "2") + ", " + tf(p16) + ", " + tf(one) + ", " + tf(a.half16) + ", " + tf(a.half16 && a.bf16) + ", 64>";
         g_kernel_tag = tag.c_str();
     }
     // short sequences (65..192 keys: the estimator's half-length level) on P16 / H16 images: one workgroup per (utterance, head),

@@ -76,7 +76,7 @@ struct VocosW {
     std::vector<Panel> pw1, pw2;
 };
 
-struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; const char* tag; };
+struct ProfRec { hipEvent_t e0, e1; int klass; double flops, bytes; std::string tag; };      // tag: a copy (launchers reuse their buffers)
 
 }  // namespace mtts
 

@@ -35,7 +35,7 @@ static int prof_begin(mtts_ctx* c, int klass, double flops, double bytes, hipStr
         HIP_OK(hipEventCreate(&e));
         c->ev_pool.push_back(e);
     }
-    ProfRec r{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], klass, flops, bytes, nullptr};
+    ProfRec r{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], klass, flops, bytes, std::string()};
     g_kernel_tag = nullptr;
     c->ev_used += 2;
     HIP_OK(hipEventRecord(r.e0, s));
@@ -45,7 +45,7 @@ static int prof_begin(mtts_ctx* c, int klass, double flops, double bytes, hipStr
 static int prof_end(mtts_ctx* c, hipStream_t s) {
     if (!c || !c->prof_on) return 0;
     HIP_OK(hipEventRecord(c->prof.back().e1, s));
-    c->prof.back().tag = g_kernel_tag;        // (a static string of the launcher that ran in between, or null)
+    c->prof.back().tag = g_kernel_tag ? g_kernel_tag : "";        // (set by the launcher that ran in between, or null)
     return 0;
 }
 #define LAUNCH(ctx, klass, flops, stream, call)  \
@@ -1982,7 +1982,7 @@ int64_t mtts_prof_records(mtts_ctx* c, double* out, int64_t max_records) {
 int64_t mtts_prof_tags(mtts_ctx* c, char* out, int64_t max_bytes) {
     if (!c || !out || max_bytes < 2) { set_error("mtts_prof_tags: bad argument"); return -1; }
     std::string all;
-    for (const ProfRec& r : c->prof) { all += r.tag ? r.tag : "-"; all += '\n'; }
+    for (const ProfRec& r : c->prof) { all += r.tag.empty() ? "-" : r.tag.c_str(); all += '\n'; }
     if ((int64_t)all.size() + 1 > max_bytes) { set_error("mtts_prof_tags: buffer too small"); return -1; }
     std::memcpy(out, all.c_str(), all.size() + 1);
     return (int64_t)c->prof.size();

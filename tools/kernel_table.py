@@ -59,7 +59,24 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--prof", default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--join", default=None, help="a <table>.json written by an earlier run: join it with --prof on a machine without a GPU")
     a = ap.parse_args()
+    if a.join:
+        rows, rp = json.loads(Path(a.join).read_text()), rocprof(a.prof)
+        f = lambda v, fmt: "" if v is None else format(v, fmt)
+        lines = ["| instantiation | launches/step | mean us (events) | GFLOP/launch | TFLOP/s | frac of peak | % of kernel time | mean us (rocprofv3) | MFMA busy | HBM read MB | HBM write MB |",
+                 "|---|---|---|---|---|---|---|---|---|---|---|"]
+        for r in rows:
+            q = rp.get(r["instantiation"], {})
+            r.update({k: q.get(k) for k in ("avg_us", "busy", "read_mb", "write_mb")})
+            lines.append(f"| `{r['instantiation']}` | {r['launches_per_step']:.0f} | {r['mean_us']:.1f} | {r['gflop_per_launch']:.3f} | {r['tflops']:.1f} | {r['frac']:.3f} | "
+                         f"{r['time_pct']:.1f} | {f(r.get('avg_us'), '.1f')} | {f(r.get('busy'), '.3f')} | {f(r.get('read_mb'), '.2f')} | {f(r.get('write_mb'), '.2f')} |")
+        text = "\n".join(lines) + "\n"
+        print(text)
+        if a.out:
+            Path(a.out).write_text(text)
+            Path(a.out).with_suffix(".json").write_text(json.dumps(rows, indent=1))
+        return
     hparams = importlib.import_module(PKG + ".hparams")
     synthetic = importlib.import_module(PKG + ".synthetic")
     inference = importlib.import_module(PKG + ".inference")

@@ -51,7 +51,7 @@ def main():
         rows.append({"kernel": k, "launches_in_pmc_run": n, "hbm_read_mb_per_launch": round(rd / 1e6, 2),
                      "hbm_write_mb_per_launch": round(wr / 1e6, 2), "avg_us_kernel_trace": round(avg_us, 1), "time_pct": pct,
                      "hbm_gb_per_s": round((rd + wr) / max(avg_us, 1e-9) / 1e3, 1)})
-        if k.startswith("gemm_f32_kernel") or k.startswith("gemm_p16_kernel"):
+        if k.startswith(("gemm_f32_kernel", "gemm_p16_kernel", "tblock_chain_kernel")):     # the launches bench.py counts as GEMM
             g_bytes += (rd + wr) * n
             g_n += n
     # MFMA-pipe busy fraction per kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024)
