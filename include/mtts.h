@@ -28,7 +28,7 @@ extern "C" {
 
 #define MTTS_ABI_VERSION 2
 /* bumped whenever the packed weight image changes layout (invalidates mtts_export_weights caches) */
-#define MTTS_IMAGE_REVISION 3
+#define MTTS_IMAGE_REVISION 4
 
 typedef struct mtts_ctx mtts_ctx;
 

@@ -193,12 +193,9 @@ struct ChainArgs {
     int ld_x = 0;
     const _Float16* wstream = nullptr;   // fragment stream of the whole chain (chain_stream_pack), [8 waves][frags][64 lanes][8 halves]
     long stream_frags = 0;               // fragments per wave incl. the tail padding
-    const float* b_out = nullptr;        // [C]
-    const float* b1 = nullptr;           // [4C]  FF first projection: bias with the LayerNorm shift folded in
-    const float* wsum1 = nullptr;        // [4C]  row sums of the folded panel (LayerNorm applied after the product)
-    const float* p0 = nullptr;           // [4C]  SnakeBeta exp(alpha)
-    const float* p1 = nullptr;           // [4C]  SnakeBeta 1 / (exp(beta) + 1e-9)
-    const float* b2 = nullptr;           // [C]
+    // column constants, ONE block of 18 C floats: rowsum(W1') | b1' (LayerNorm shift folded in) | SnakeBeta exp(alpha) |
+    // SnakeBeta 1 / (exp(beta) + 1e-9) (4 C each) | out-projection bias (zeros without that phase) | b2 (C each)
+    const float* consts = nullptr;
     const float* b_qkv = nullptr;        // [3 * inner] or null: no q|k|v phase
     const float* wsum_qkv = nullptr;
     int n_qkv = 0;                       // 3 * inner
@@ -210,6 +207,7 @@ struct ChainArgs {
     float eps = 1e-5f;
     unsigned int* range_flag = nullptr;
     int qb = 0, ch = 0;                  // rows per workgroup (64 / 48 / 32) and hidden chunk (128 / 256) the stream was packed for
+    int pf_wgs = 0;                      // extra workgroups (lowest ids) that only touch the weight stream ahead of the others; 8 = one per XCD
     unsigned long long* kstamp = nullptr;// diagnostic builds only (-DMTTS_CHAIN_STAMP): 16 phase stamps of workgroup 0
 };
 // fragments per wave of the stream for (C, inner, hidden chunk, q|k|v width), incl. the padding the register ring may run into

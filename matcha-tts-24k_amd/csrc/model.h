@@ -39,6 +39,7 @@ struct TBlockW {
     // when another block of the same run follows -- that block's q|k|v projection.  0 frags = chain not packed for this block.
     size_t chain = 0;          // offset in the image (floats)
     long chain_frags = 0;
+    size_t chain_consts = 0;   // the chain kernel's column constants as one block of 18 C floats (kernels.h ChainArgs::consts)
     int chain_ch = 0;          // hidden chunk the stream was packed for
     int chain_nqkv = 0;        // width of the q|k|v part (0: none)
     int next = -1;             // index of the block whose q|k|v the chain computes

@@ -73,9 +73,15 @@ static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
+// prefetch workgroups of the chain launch (tblock_chain.hip): one per XCD; MTTS_CHAIN_PF=<n> (0: none) for A/B runs
+static int chain_prefetch_wgs() {
+    static const int n = [] { const char* e = getenv("MTTS_CHAIN_PF"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    return n;
+}
 static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
     ChainArgs a = a0;
     a.range_flag = c->cur_flag;
+    a.pf_wgs = chain_prefetch_wgs();
     LAUNCHB(c, 0, chain_flops(a), chain_bytes(a), s, launch_tblock_chain(a, s));
     return 0;
 }
@@ -605,9 +611,19 @@ static int pack_all(mtts_ctx* c, bool dry = false) {
             t.chain_nqkv = nq;
             t.next = nq ? (int)k + 1 : -1;
             t.chain = P.alloc((size_t)t.chain_frags * CHAIN_WAVES * 256);
-            if (!dry) chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
-                              nq ? &c->image[D.tb[k + 1].qkv.w] : nullptr, reinterpret_cast<uint16_t*>(&c->image[t.chain]),
-                              &c->weights_saturate);
+            t.chain_consts = P.alloc((size_t)18 * C);
+            if (!dry) {
+                chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
+                                  nq ? &c->image[D.tb[k + 1].qkv.w] : nullptr, reinterpret_cast<uint16_t*>(&c->image[t.chain]),
+                                  &c->weights_saturate);
+                float* cc = &c->image[t.chain_consts];          // the chain kernel's column constants as one block (kernels.h)
+                std::memcpy(cc, &c->image[t.ff1.wsum], (size_t)4 * C * sizeof(float));
+                std::memcpy(cc + 4 * C, &c->image[t.ff1.b], (size_t)4 * C * sizeof(float));
+                std::memcpy(cc + 8 * C, &c->image[t.alpha_exp.off], (size_t)4 * C * sizeof(float));
+                std::memcpy(cc + 12 * C, &c->image[t.inv_beta.off], (size_t)4 * C * sizeof(float));
+                std::memcpy(cc + 16 * C, &c->image[t.out.b], (size_t)C * sizeof(float));
+                std::memcpy(cc + 17 * C, &c->image[t.ff2.b], (size_t)C * sizeof(float));
+            }
         }
     }
     if (!P.ok) { set_error(P.why); return -1; }
@@ -852,8 +868,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
             a.att16 = ATT16; a.ld_att = 2 * inner;
             a.x16 = d.X16; a.ld_x = 2 * C;
             a.wstream = reinterpret_cast<const _Float16*>(W(c, t.chain)); a.stream_frags = t.chain_frags;
-            a.b_out = W(c, t.out.b); a.b1 = W(c, t.ff1.b); a.wsum1 = W(c, t.ff1.wsum);
-            a.p0 = W(c, t.alpha_exp.off); a.p1 = W(c, t.inv_beta.off); a.b2 = W(c, t.ff2.b);
+            a.consts = W(c, t.chain_consts);
             if (emit_stats) {                 // another block follows: its q|k|v leaves this launch, x stays unmasked
                 const TBlockW& nx = c->dec.tb[t.next];
                 a.b_qkv = W(c, nx.qkv.b); a.wsum_qkv = W(c, nx.qkv.wsum); a.n_qkv = nx.qkv.N;
@@ -1898,10 +1913,11 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
     ChainArgs a;
     a.M = M; a.C = C; a.inner = inner; a.att16 = att16; a.ld_att = 2 * inner; a.x16 = x16; a.ld_x = 2 * C;
     a.wstream = d_stream; a.stream_frags = frags;
-    a.wsum1 = d_c; a.b1 = d_c + 4 * C; a.p0 = d_c + 8 * C; a.p1 = d_c + 12 * C; a.b_out = d_c + 16 * C; a.b2 = d_c + 17 * C;
+    a.consts = d_c;
     if (n_qkv) { a.wsum_qkv = d_c + 18 * C; a.b_qkv = d_c + 18 * C + n_qkv; a.n_qkv = n_qkv; a.qkv16 = q16; a.ld_qkv = 2 * n_qkv; }
     a.x_out = xo16; a.ld_out = 2 * C; a.x_out_mask = d_out_mask;
     a.qb = qb; a.ch = ch;
+    a.pf_wgs = chain_prefetch_wgs();
 #ifdef MTTS_CHAIN_STAMP
     a.kstamp = reinterpret_cast<unsigned long long*>(d_qkv_out);      // (diagnostic build: the stamps land in the q|k|v output buffer)
 #endif

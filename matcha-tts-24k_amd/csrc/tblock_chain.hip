@@ -127,7 +127,7 @@ void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, 
 // ------------------------------------------------------------------------------------------------ device
 // diagnostic builds (-DMTTS_CHAIN_STAMP, tools/chain_sweep.py --stamps): s_memtime of wave 0 of workgroup 0 at the phase boundaries
 #ifdef MTTS_CHAIN_STAMP
-#define CH_STAMP(i) do { if (p.kstamp && blockIdx.x == 0 && tid == 0) p.kstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_STAMP(i) do { if (p.kstamp && wg == 0 && tid == 0) p.kstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CH_STAMP(i) do { } while (0)
 #endif
@@ -177,16 +177,37 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4, swz = (c >> 1) & 7;     // fragment coordinates: row / channel c, k block q
-    const int M = p.M, m0 = blockIdx.x * QB;
+    const int wg = (int)blockIdx.x - p.pf_wgs;                      // the first pf_wgs workgroups only prefetch (below)
+    const int M = p.M, m0 = wg * QB;
     const bool has_out = p.inner > 0, has_qkv = p.b_qkv != nullptr;
     const unsigned int lane16 = lane * 16;                          // per-lane byte offset of the stream loads
     CH_STAMP(0);
+    // ---- prefetch workgroups (ChainArgs::pf_wgs, the lowest workgroup ids: dispatched first, round-robin over the XCDs).  Every
+    // computing workgroup of an XCD reads the SAME stream addresses at about the same time, so each line is ONE L2 miss that all
+    // of them wait for, and the window in flight per XCD is a single workgroup's ring (96 KB at the miss latency: the 50-70 GB/s
+    // per CU measured in round 3).  A workgroup per XCD that does nothing but touch the stream ahead of them -- a 128-byte line per
+    // lane, 8 KiB per instruction and wave, 8 instructions in flight per wave -- turns those misses into hits: -20 us per launch
+    // at the full-length level, and the chain at the half-length level stops losing to the tiled launches.
+    if (wg < 0) {
+        const char* base = reinterpret_cast<const char*>(p.wstream) + (size_t)wave * (size_t)p.stream_frags * 1024;
+        const long bytes = (long)p.stream_frags * 1024;
+        unsigned int sink = 0;
+        for (long off = (long)(p.pf_wgs + wg) / 8 * 8192; off < bytes; off += 8192 * ((p.pf_wgs + 7) / 8)) {
+            const long o = off + lane * 128;                        // (several prefetch workgroups per XCD interleave their 8 KiB pieces)
+            const unsigned int ob = (unsigned int)(o < bytes ? o : bytes - 128);
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(ob), "s"(base));
+            asm volatile("s_waitcnt vmcnt(8)");
+        }
+        asm volatile("s_waitcnt vmcnt(0)");
+        asm volatile("" : "+v"(sink));
+        return;
+    }
 #ifdef MTTS_CHAIN_DUMP
     // diagnostic: copies of the LDS regions at the phase boundaries, per workgroup [x0 | ct | x1 | srow | h0 | x2] (p.kstamp = base)
     constexpr int DUMP_WG = 3 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4 + K::HT_BYTES;
     auto dump = [&](int sect_off, const char* src, int bytes) {
         if (!p.kstamp) return;
-        char* dst = reinterpret_cast<char*>(p.kstamp) + (size_t)blockIdx.x * DUMP_WG + sect_off;
+        char* dst = reinterpret_cast<char*>(p.kstamp) + (size_t)wg * DUMP_WG + sect_off;
         for (int o = tid * 16; o < bytes; o += 64 * CHAIN_NW * 16) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
     };
 #define CH_DUMP(off, src, bytes) dump(off, src, bytes)
@@ -227,15 +248,13 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         for (int g0 = 0; g0 < KG; ++g0) xv[g0] = *reinterpret_cast<const f16x8*>(src + g0 * 64);
         constexpr int NCT = (K::CT_FLOATS / 4 + 64 * CHAIN_NW - 1) / (64 * CHAIN_NW);      // f32x4 per thread
         f32x4 cv[NCT];
+        // one contiguous block (ChainArgs::consts), unconditional loads: a branch around a load makes hipcc wait for each one
+        // separately -- the six-pointer version of this prologue spent three dependent round trips here
 #pragma unroll
         for (int n = 0; n < NCT; ++n) {
             const int idx = (tid + n * 64 * CHAIN_NW) * 4;
-            const int seg = idx < 16 * C ? idx / (4 * C) : 4 + (idx - 16 * C) / C;
-            const int o = idx < 16 * C ? idx - seg * 4 * C : idx - 16 * C - (seg - 4) * C;
-            const float* srcc = seg == 0 ? p.wsum1 : seg == 1 ? p.b1 : seg == 2 ? p.p0 : seg == 3 ? p.p1 : seg == 4 ? p.b_out : p.b2;
-            cv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < K::CT_FLOATS && srcc) cv[n] = *reinterpret_cast<const f32x4*>(srcc + o);
-            if (seg == 3) cv[n] *= 0.5f;
+            cv[n] = *reinterpret_cast<const f32x4*>(p.consts + min(idx, K::CT_FLOATS - 4));
+            cv[n] *= (idx >= 12 * C && idx < 16 * C) ? 0.5f : 1.0f;            // SnakeBeta: 1 / (2 (exp(beta) + 1e-9))
         }
         if (st_on) {
 #pragma unroll
@@ -541,7 +560,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     // diagnostic: per workgroup [HW_ID, XCC_ID, hash of the constants in LDS, hash of the kernel arguments as this wave holds them,
     // hash of the row statistics, -, -, -] (p.kstamp = base, zeroed by the host)
     if (p.kstamp) {
-        unsigned int* rec = reinterpret_cast<unsigned int*>(p.kstamp) + (size_t)blockIdx.x * 8;
+        unsigned int* rec = reinterpret_cast<unsigned int*>(p.kstamp) + (size_t)wg * 8;
         unsigned int hc = 0, hs = 0;
         for (int i = tid; i < K::CT_FLOATS; i += 64 * CHAIN_NW) hc ^= (__float_as_uint(CT[i]) + 0x9e3779b9u * (unsigned)i) * 2654435761u;
         for (int i = tid; i < 2 * QB; i += 64 * CHAIN_NW) hs ^= (__float_as_uint(srow[i]) + 0x9e3779b9u * (unsigned)i) * 2654435761u;
@@ -578,14 +597,15 @@ static hipError_t launch_chain_shape(const ChainArgs& a, hipStream_t s) {
     }
     static const std::string tag = "tblock_chain_kernel<" + std::to_string(C) + ", " + std::to_string(QB) + ", " + std::to_string(CH) + ">";
     g_kernel_tag = tag.c_str();
-    hipLaunchKernelGGL(kern, dim3((a.M + QB - 1) / QB), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + QB - 1) / QB + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_tblock_chain(const ChainArgs& a, hipStream_t s) {
-    if (a.M <= 0 || !a.x16 || !a.wstream || !a.x_out || !a.b1 || !a.wsum1 || !a.p0 || !a.p1 || !a.b2) return hipErrorInvalidValue;
+    if (a.pf_wgs < 0 || a.pf_wgs > 64) return hipErrorInvalidValue;
+    if (a.M <= 0 || !a.x16 || !a.wstream || !a.x_out || !a.consts) return hipErrorInvalidValue;
     if (!chain_supported(a.C, a.inner, a.n_qkv)) return hipErrorInvalidValue;
-    if (a.inner && (!a.att16 || !a.b_out || a.ld_att < 2 * a.inner || (a.ld_att & 7))) return hipErrorInvalidValue;
+    if (a.inner && (!a.att16 || a.ld_att < 2 * a.inner || (a.ld_att & 7))) return hipErrorInvalidValue;
     if (a.b_qkv && (!a.wsum_qkv || !a.qkv16 || a.n_qkv <= 0 || a.ld_qkv < 2 * a.n_qkv || (a.ld_qkv & 3))) return hipErrorInvalidValue;
     if (a.ld_x < 2 * a.C || (a.ld_x & 7) || a.ld_out < 2 * a.C || (a.ld_out & 7)) return hipErrorInvalidValue;
     if (a.stream_frags != chain_stream_frags(a.C, a.inner, a.ch, a.b_qkv ? a.n_qkv : 0)) return hipErrorInvalidValue;
