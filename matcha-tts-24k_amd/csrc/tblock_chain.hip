@@ -127,7 +127,9 @@ void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, 
 // ------------------------------------------------------------------------------------------------ device
 // diagnostic builds (-DMTTS_CHAIN_STAMP, tools/chain_sweep.py --stamps): s_memtime of wave 0 of workgroup 0 at the phase boundaries
 #ifdef MTTS_CHAIN_STAMP
-#define CH_STAMP(i) do { if (p.kstamp && wg == 0 && tid == 0) p.kstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_STAMP(i) do { if (p.kstamp && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (wg == 0) p.kstamp[i] = t_; \
+        if ((i) == 0) p.kstamp[16 + 2 * wg] = t_; if ((i) == 12) p.kstamp[17 + 2 * wg] = t_; \
+        if (wg == 0 && ((i) == 0 || (i) == 12)) p.kstamp[16 + 2 * ((M + QB - 1) / QB + p.pf_wgs) + ((i) == 12)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define CH_STAMP(i) do { } while (0)
 #endif
@@ -183,15 +185,19 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     const unsigned int lane16 = lane * 16;                          // per-lane byte offset of the stream loads
     CH_STAMP(0);
     // ---- prefetch workgroups (ChainArgs::pf_wgs, the lowest workgroup ids: dispatched first, round-robin over the XCDs).  Every
-    // computing workgroup of an XCD reads the SAME stream addresses at about the same time, so each line is ONE L2 miss that all
-    // of them wait for, and the window in flight per XCD is a single workgroup's ring (96 KB at the miss latency: the 50-70 GB/s
-    // per CU measured in round 3).  A workgroup per XCD that does nothing but touch the stream ahead of them -- a 128-byte line per
-    // lane, 8 KiB per instruction and wave, 8 instructions in flight per wave -- turns those misses into hits: -20 us per launch
-    // at the full-length level, and the chain at the half-length level stops losing to the tiled launches.
+    // computing workgroup of an XCD reads the SAME stream addresses at about the same time, so inside the model (other kernels have
+    // emptied the L2s) each line is ONE L2 miss that all of them wait for.  A workgroup per XCD that does nothing but touch the
+    // stream -- a 128-byte line per lane, 8 KiB per instruction and wave -- runs at the CU's line-fill rate (~37 B/clk: it takes
+    // ~195k cycles for the 7 MB, about as long as a computing workgroup, so it stays just ahead of them without pacing; a wider
+    // window, sleeps or more prefetchers per XCD measured the same) and turns those misses into hits: a computing workgroup's
+    // lifetime 117 -> 99 us (32 rows) / 134 -> 116 us (48 rows) on the 100 MHz real-time counter, -0.5..0.7 ms per bench step.
     if (wg < 0) {
         const char* base = reinterpret_cast<const char*>(p.wstream) + (size_t)wave * (size_t)p.stream_frags * 1024;
         const long bytes = (long)p.stream_frags * 1024;
         unsigned int sink = 0;
+#ifdef MTTS_CHAIN_STAMP
+        if (p.kstamp && tid == 0) p.kstamp[16 + 2 * ((M + QB - 1) / QB + p.pf_wgs + wg)] = __builtin_amdgcn_s_memtime();
+#endif
         for (long off = (long)(p.pf_wgs + wg) / 8 * 8192; off < bytes; off += 8192 * ((p.pf_wgs + 7) / 8)) {
             const long o = off + lane * 128;                        // (several prefetch workgroups per XCD interleave their 8 KiB pieces)
             const unsigned int ob = (unsigned int)(o < bytes ? o : bytes - 128);
@@ -200,6 +206,10 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         }
         asm volatile("s_waitcnt vmcnt(0)");
         asm volatile("" : "+v"(sink));
+#ifdef MTTS_CHAIN_STAMP
+        __syncthreads();
+        if (p.kstamp && tid == 0) p.kstamp[17 + 2 * ((M + QB - 1) / QB + p.pf_wgs + wg)] = __builtin_amdgcn_s_memtime();
+#endif
         return;
     }
 #ifdef MTTS_CHAIN_DUMP

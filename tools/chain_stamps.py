@@ -31,6 +31,29 @@ def main():
         for i in range(1, 12):
             print(f"   {st[i] - prev:8d}  {NAMES[i]}")
             prev = st[i]
+        nwg = (M + qb - 1) // qb
+        allst = q.view(-1).view(torch.int64)[16:16 + 2 * nwg].cpu().view(nwg, 2)
+        t0 = int(allst[:, 0].min())
+        life = (allst[:, 1] - allst[:, 0]).double()
+        end = (allst[:, 1] - t0).double()
+        startd = (allst[:, 0] - t0).double()
+        print(f"   all {nwg} workgroups: lifetime min / median / max {int(life.min())} / {int(life.median())} / {int(life.max())} cycles; "
+              f"start spread {int(startd.max())}; last end {int(end.max())} after the first start")
+        import os
+        npf = int(os.environ.get("MTTS_CHAIN_PF", "8"))
+        if npf:
+            pfs = q.view(-1).view(torch.int64)[16 + 2 * nwg:16 + 2 * (nwg + npf)].cpu().view(npf, 2)
+            print("   prefetch workgroups' lifetimes (cycles):", (pfs[:, 1] - pfs[:, 0]).tolist())
+        rt = q.view(-1).view(torch.int64)[16 + 2 * (nwg + npf):18 + 2 * (nwg + npf)].cpu().tolist()
+        print(f"   workgroup 0: {st[12] - st[0]} shader cycles in {rt[1] - rt[0]} ticks of the 100 MHz real-time counter = {(rt[1] - rt[0]) / 100.0:.1f} us "
+              f"-> {(st[12] - st[0]) / max(1, rt[1] - rt[0]) * 0.1:.2f} GHz")
+        for x in range(8):
+            sel = torch.arange(nwg) % 8 == x
+            st_x, en_x = allst[sel, 0], allst[sel, 1]
+            order = torch.argsort(st_x)
+            gaps = (st_x[order][1:] - st_x[order][:-1]).tolist()
+            print(f"     XCD {x}: {int(sel.sum())} workgroups, lifetime median {int(life[sel].median())} max {int(life[sel].max())}; "
+                  f"first start -> last start {int(st_x.max() - st_x.min())}, first start -> last end {int(en_x.max() - st_x.min())} cycles; start gaps {gaps[:8]}")
         for i, name in ((13, "q|k|v: LayerNorm moments + constants + pass 0 k-loop"), (14, "pass 0 epilogue + pass 1 k-loop"),
                         (15, "pass 1 epilogue + pass 2 k-loop"), (12, "pass 2 epilogue")):
             print(f"   {st[i] - prev:8d}  {name}")
