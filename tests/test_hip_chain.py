@@ -111,3 +111,26 @@ def test_chain_masked_rows_and_exact_row_independence(hip):
     # and with 32-row workgroups
     small, q_small = hip.tblock_chain(a, x, *args[2:10], w_qkv=args[10], b_qkv=args[11], qb=32, ch=128)
     assert torch.equal(small, plain) and torch.equal(q_small, q_plain)
+
+
+def test_prefetch_workgroups_do_not_change_results(hip):
+    """The chain launch's prefetch workgroups (MTTS_CHAIN_PF, read once per process; default 8) only touch the weight stream:
+    0, 8 and 24 of them give bitwise the same outputs (one subprocess per setting), a partly filled last workgroup included."""
+    import hashlib, os, subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, hashlib, importlib, torch\n"
+        f"sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r})\n"
+        "hip = importlib.import_module('matcha-tts-24k_amd._hip')\n"
+        "from test_hip_chain import make_case\n"
+        "case = make_case(700, 384, 384, 1152, seed=3)\n"
+        "dev = torch.device('cuda')\n"
+        "xo, q = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], w_qkv=case[10], b_qkv=case[11], qb=48, ch=256)\n"
+        "print('HASH', hashlib.sha256(xo.cpu().numpy().tobytes() + q.cpu().numpy().tobytes()).hexdigest())\n")
+    hashes = {}
+    for pf in ("0", "8", "24"):
+        env = dict(os.environ, MTTS_CHAIN_PF=pf)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes[pf] = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("HASH")][0]
+    assert len(set(hashes.values())) == 1, hashes
