@@ -101,11 +101,6 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_p16_kernel(con
     float* srow = reinterpret_cast<float*>(lds + p16_main_bytes(BM, NST, KS));
 
     const int tid_all = threadIdx.x;
-    if constexpr (KS == 1) {
-        if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles
-        }
-    }
     const int ks = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid_all >> 8);      // which part of the K axis (wave-uniform)
     const int tid = tid_all & 255, lane = tid & 63;                                 // position inside the 4-wave set
     // the wave index as a SCALAR: every LDS destination of a DMA piece is then an SGPR expression (s_add + s_mov m0) instead of
@@ -645,11 +640,6 @@ hipError_t launch_gemm_p16(const GemmArgs& a_in, hipStream_t s) {
     }
     int nst = 2;
     const int bm = p16_choose(a, nst);
-    {
-        static const int stagger = [] { const char* e = getenv("MTTS_P16_STAGGER"); return e ? atoi(e) : 0; }();
-        const int tiles = ((a.B * a.T_out + bm - 1) / bm) * ((a.N + GEMM_BN - 1) / GEMM_BN);
-        a.stagger = tiles > 256 ? stagger : 0;
-    }
 #ifdef MTTS_KSTAMP
     if (g_kstamp && g_kstamp_skip > 0) {
         --g_kstamp_skip;

@@ -114,10 +114,6 @@ struct GemmArgs {
     // diagnostic builds only (-DMTTS_KSTAMP, tools/kstamp.py): per workgroup 8 words = s_memtime at kernel start, first tile
     // landed, loop end, epilogue end, then s_memrealtime at start and end.  No output value depends on them.
     unsigned long long* kstamp = nullptr;
-    // P16 kernel, grids of more than one workgroup per CU: workgroups 256..511, 768..1023, ... (the SECOND one dispatched to each
-    // CU in a round) start `stagger` x 1024 cycles late, so that one resident workgroup's epilogue (vector ALU) runs beside the
-    // other's k-loop (matrix pipe) instead of both doing the same thing at the same time.  Set by launch_gemm_p16 (MTTS_P16_STAGGER).
-    int stagger = 0;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_p16(const GemmArgs& a, hipStream_t s);      // called by launch_gemm when a.a16_0 is set
