@@ -100,7 +100,7 @@ struct mtts_ctx {
     bool chain_on = true;         // transformer blocks' row-local part as one launch (tblock_chain.hip; MTTS_CHAIN=0 at mtts_create disables)
     int chain_ch = 256;           // hidden chunk of the chain's FeedForward at width 384 (MTTS_CHAIN_CH at mtts_create: 128 / 256)
     int chain_qb = 0;             // rows per workgroup (MTTS_CHAIN_QB at mtts_create; 0 = by shape)
-    int chain_min_rows = 8192;    // estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS):
+    int chain_min_rows = 6000;    // estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS):
                                   // measured at width 384 -- 10304 rows: 138 vs ~160 us per block; 5152 rows: 100 vs ~92 us (profiles/r03_chain_*)
     mtts::DecW dec;
     mtts::EncW enc;
