@@ -879,9 +879,11 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
             else { a.x_out = d.X16; a.ld_out = 2 * C; }
             a.ch = t.chain_ch;
             // rows per workgroup: the largest the packed hidden chunk's kernel shapes have (fewer workgroups = fewer copies of the
-            // weight stream), 32 below 8192 rows so that the grid still covers the chip
+            // weight stream), 32 while that many workgroups are still one round of the chip
             const int qb_big = a.ch == 256 ? 48 : 64;
-            a.qb = (c->chain_qb == 32 || c->chain_qb == qb_big) ? c->chain_qb : (M >= 8192 ? qb_big : 32);
+            // (one round of the 256 CUs, the prefetch workgroups included: 32-row workgroups up to 7936 rows)
+            const bool fits32 = (M + 31) / 32 + chain_prefetch_wgs() <= 256;
+            a.qb = (c->chain_qb == 32 || c->chain_qb == qb_big) ? c->chain_qb : (fits32 ? 32 : qb_big);
 #ifdef MTTS_CHAIN_VERIFY
             RET_IF(run_chain_verified(c, a, FF16, s));
 #else
