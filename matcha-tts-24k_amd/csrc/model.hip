@@ -82,6 +82,10 @@ static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
     ChainArgs a = a0;
     a.range_flag = c->cur_flag;
     a.pf_wgs = chain_prefetch_wgs();
+    if (a.qb > 0) {           // a grid that is exactly one round of the chip is not pushed into a second one by its prefetchers
+        const int nwg = (a.M + a.qb - 1) / a.qb;
+        if (nwg <= 256 && nwg + a.pf_wgs > 256) a.pf_wgs = 0;
+    }
     LAUNCHB(c, 0, chain_flops(a), chain_bytes(a), s, launch_tblock_chain(a, s));
     return 0;
 }
