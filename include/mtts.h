@@ -236,6 +236,9 @@ int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, in
  * halves with lane (r = lane & 15, q = lane >> 4) holding panel row n0 + r, columns k0 + 8 q .. + 7 (the A operand of
  * v_mfma_f32_16x16x32_f16).  h_dst: mtts_chain_stream_frags(...) * 8 * 512 halves. */
 int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv);
+/* The model's launch plan of a chain launch over M rows (hidden chunk ch = 128 / 256): rows per workgroup and the number of
+ * prefetch workgroups (MTTS_CHAIN_PF, default 8).  Host arithmetic only. */
+int mtts_chain_plan(int M, int ch, int* qb, int* prefetch_wgs);
 int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
                            const float* h_w_qkv, uint16_t* h_dst);
 int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch);

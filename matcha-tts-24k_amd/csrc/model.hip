@@ -78,14 +78,21 @@ static int chain_prefetch_wgs() {
     static const int n = [] { const char* e = getenv("MTTS_CHAIN_PF"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
     return n;
 }
+// Launch plan of a chain launch over M rows (hidden chunk ch; qb_forced = MTTS_CHAIN_QB or 0): rows per workgroup and prefetch
+// workgroups.  32-row workgroups while they -- with the prefetchers -- are one round of the 256 CUs (a 32-row workgroup lives 99 us, a
+// 48-row one 116 us: both are bound by the 7 MB they stream, profiles/r03_chain_prefetch_stamps.log), the largest shape beyond; no
+// prefetchers when they would push a one-round grid into a second round.
+static void chain_plan(int M, int ch, int qb_forced, int* qb, int* pf) {
+    const int qb_big = ch == 256 ? 48 : 64, want = chain_prefetch_wgs();
+    const bool fits32 = (M + 31) / 32 + want <= 256;
+    *qb = (qb_forced == 32 || qb_forced == qb_big) ? qb_forced : (fits32 ? 32 : qb_big);
+    const int nwg = (M + *qb - 1) / *qb;
+    *pf = (nwg <= 256 && nwg + want > 256) ? 0 : want;
+}
 static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
     ChainArgs a = a0;
     a.range_flag = c->cur_flag;
-    a.pf_wgs = chain_prefetch_wgs();
-    if (a.qb > 0) {           // a grid that is exactly one round of the chip is not pushed into a second one by its prefetchers
-        const int nwg = (a.M + a.qb - 1) / a.qb;
-        if (nwg <= 256 && nwg + a.pf_wgs > 256) a.pf_wgs = 0;
-    }
+    { int qb_unused = 0; chain_plan(a.M, a.ch, a.qb, &qb_unused, &a.pf_wgs); }
     LAUNCHB(c, 0, chain_flops(a), chain_bytes(a), s, launch_tblock_chain(a, s));
     return 0;
 }
@@ -882,12 +889,7 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
             } else if (last16) { a.x_out = last16; a.ld_out = 2 * C; a.x_out_mask = d.mask[lvl]; }
             else { a.x_out = d.X16; a.ld_out = 2 * C; }
             a.ch = t.chain_ch;
-            // rows per workgroup: the largest the packed hidden chunk's kernel shapes have (fewer workgroups = fewer copies of the
-            // weight stream), 32 while that many workgroups are still one round of the chip
-            const int qb_big = a.ch == 256 ? 48 : 64;
-            // (one round of the 256 CUs, the prefetch workgroups included: 32-row workgroups up to 7936 rows)
-            const bool fits32 = (M + 31) / 32 + chain_prefetch_wgs() <= 256;
-            a.qb = (c->chain_qb == 32 || c->chain_qb == qb_big) ? c->chain_qb : (fits32 ? 32 : qb_big);
+            { int pf_unused = 0; chain_plan(M, a.ch, c->chain_qb, &a.qb, &pf_unused); }
 #ifdef MTTS_CHAIN_VERIFY
             RET_IF(run_chain_verified(c, a, FF16, s));
 #else
@@ -1852,6 +1854,12 @@ int mtts_groupnorm_mish(const float* d_y, const float* d_gamma, const float* d_b
 // panels (LayerNorm affines already folded: w1 / b1 for the FeedForward, w_qkv / b_qkv for the following block) are packed into a
 // fragment stream on the host, and the P16 outputs are decoded back to fp32.  w_qkv == NULL: no q|k|v phase; inner == 0: no
 // out-projection (the FeedForward alone on d_x).  h_* pointers are HOST memory, d_* device memory.
+// the model's launch plan for M rows (test entry; no GPU): rows per workgroup and prefetch workgroups
+int mtts_chain_plan(int M, int ch, int* qb, int* prefetch_wgs) {
+    if (M <= 0 || (ch != 128 && ch != 256) || !qb || !prefetch_wgs) { set_error("mtts_chain_plan: bad argument"); return -1; }
+    chain_plan(M, ch, 0, qb, prefetch_wgs);
+    return 0;
+}
 int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv) {
     if (!chain_supported(C, inner, n_qkv) || (ch != 128 && ch != 256)) { set_error("mtts_chain_stream_frags: unsupported shape"); return -1; }
     return chain_stream_frags(C, inner, ch, n_qkv);

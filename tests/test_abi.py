@@ -166,3 +166,26 @@ def test_context_refuses_concurrent_use(lib, hparams):
     assert lib.mtts_debug_hold(h.ctx, 1) == 0                       # released
     rc = lib.mtts_text_encoder_forward(h.ctx, None, None, None, None, 1, 4, None, None, None, None, 0, None)
     assert rc == -1 and b"weights not uploaded" in lib.mtts_last_error()      # the ordinary check, not the guard
+
+
+def test_chain_launch_plan_keeps_grids_to_one_round(lib):
+    """mtts_chain_plan (host arithmetic of the model's chain launches, default MTTS_CHAIN_PF = 8): 32-row workgroups while they and
+    the prefetch workgroups are one round of the 256 CUs, 48-row ones beyond (B = 25: 8050 rows -> 168 + 8, not 252 + 8), and no
+    prefetchers when they alone would push a one-round grid into a second round (B = 37: 249 workgroups)."""
+    import ctypes, os
+    if "MTTS_CHAIN_PF" in os.environ:
+        pytest.skip("MTTS_CHAIN_PF overrides the default this test states")
+    def plan(M, ch=256):
+        qb, pf = ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.mtts_chain_plan(M, ch, ctypes.byref(qb), ctypes.byref(pf)) == 0
+        return qb.value, pf.value
+    assert plan(32 * 161) == (32, 8)              # the half-length level of B = 32 (when the threshold lets it through)
+    assert plan(7936) == (32, 8)                  # 248 + 8 = 256
+    assert plan(7937) == (48, 8)
+    assert plan(25 * 322) == (48, 8)
+    assert plan(32 * 322) == (48, 8)              # 215 + 8
+    assert plan(36 * 322) == (48, 8)              # 242 + 8
+    assert plan(37 * 322) == (48, 0)              # 249 workgroups: + 8 would be a second round
+    assert plan(64 * 322) == (48, 8)              # several rounds anyway
+    assert plan(5152, ch=128) == (32, 8) and plan(10304, ch=128) == (64, 8)
+    assert lib.mtts_chain_plan(0, 256, None, None) != 0
