@@ -28,7 +28,7 @@ extern "C" {
 
 #define MTTS_ABI_VERSION 2
 /* bumped whenever the packed weight image changes layout (invalidates mtts_export_weights caches) */
-#define MTTS_IMAGE_REVISION 4
+#define MTTS_IMAGE_REVISION 5
 
 typedef struct mtts_ctx mtts_ctx;
 
@@ -251,6 +251,13 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
                             const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,
                             const float* h_b2, const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask,
                             int qb, int ch, float* d_x_out, float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms);
+/* the PAIR form of the same launch: two workgroups of one XCD share a row tile, each streams half of the FeedForward's hidden chunks
+ * and of the q|k|v passes and they exchange their FF2 partial sums through the L2 (csrc/tblock_chain.hip).  Needs an out-projection
+ * (inner > 0), an even number of hidden chunks and a grid that is resident at once: 16 * ceil(ceil(M / qb) / 8) + 16 <= 256. */
+int mtts_tblock_chain_pair_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                                 const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,
+                                 const float* h_b2, const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask,
+                                 int qb, int ch, float* d_x_out, float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms);
 
 /* Row statistics for LayerNorm over C (biased variance, eps inside rsqrt): mean[M], rstd[M]. */
 int mtts_row_stats(const float* d_x, int M, int C, int ld, float eps, float* d_mean, float* d_rstd, void* stream);

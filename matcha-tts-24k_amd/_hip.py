@@ -159,6 +159,8 @@ def load() -> C.CDLL:
         "mtts_tblock_chain": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]),
         "mtts_tblock_chain_timed": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp,
                                           i32, C.POINTER(C.c_float)]),
+        "mtts_tblock_chain_pair_timed": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp,
+                                          i32, C.POINTER(C.c_float)]),
         "mtts_row_stats": (i32, [vp, i32, i32, i32, f32, vp, vp, vp]),
         "mtts_channel_layernorm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp]),
         "mtts_groupnorm_scratch_bytes": (i64, [i32, i32, i32]),
@@ -356,6 +358,14 @@ class HipModel:
         sp = stream_ptr()
         parts = [self._last_ws[(k, sp)][:4].view(torch.int32) if (k, sp) in self._last_ws else z for k in ("enc", "dec")]
         return torch.cat(parts)
+
+    def pair_timeouts(self) -> torch.Tensor:
+        """Second word of this stream's latest estimator workspace header: non-zero = a workgroup of a pair-form chain launch waited in
+        vain for its partner (csrc/tblock_chain.hip) -- the call's results are void.  A device int32 tensor [1]."""
+        sp = stream_ptr()
+        if ("dec", sp) not in self._last_ws:
+            return torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._last_ws[("dec", sp)][4:8].view(torch.int32)
 
     def weights_saturate(self) -> bool:
         r = self.lib.mtts_weights_saturate(self.ctx)
@@ -573,7 +583,7 @@ def _host(t):
     return a, a.ctypes.data
 
 
-def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv=None, out_mask=None, qb=64, ch=128, repeat=0):
+def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv=None, out_mask=None, qb=64, ch=128, repeat=0, pair=False):
     """Row-local chain of a transformer block (csrc/tblock_chain.hip, include/mtts.h mtts_tblock_chain).  att [M, inner] (or None:
     FeedForward only), x [M, C] on the device; panels / vectors anywhere (copied to the host).  Returns (x_out, qkv or None)."""
     lib = load()
@@ -589,7 +599,7 @@ def tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=None, b_qkv
     keep = [_host(t) for t in (w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv, b_qkv)]
     hp = [k[1] for k in keep]
     ms = C.c_float(0.0)
-    check(lib.mtts_tblock_chain_timed(ptr(att), ptr(x), M, Cc, inner, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
+    check((lib.mtts_tblock_chain_pair_timed if pair else lib.mtts_tblock_chain_timed)(ptr(att), ptr(x), M, Cc, inner, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
                                       n_qkv, ptr(out_mask), qb, ch, ptr(x_out), ptr(qkv), scratch.data_ptr(), stream_ptr(), repeat,
                                       C.byref(ms)))
     torch.cuda.synchronize()

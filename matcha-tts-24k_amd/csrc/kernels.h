@@ -203,6 +203,12 @@ struct ChainArgs {
     float eps = 1e-5f;
     unsigned int* range_flag = nullptr;
     int qb = 0, ch = 0;                  // rows per workgroup (64 / 48 / 32) and hidden chunk (128 / 256) the stream was packed for
+    // pair form (tblock_chain.hip): two workgroups of one XCD per row tile, each streams half of the FeedForward's chunks and of
+    // the q|k|v passes; FF2 partial sums meet in `pair_part` [2 tiles][QB][C] fp32 behind the flags `pair_flag` [2 tiles] == pair_epoch
+    int pair = 0;
+    float* pair_part = nullptr;
+    unsigned int* pair_flag = nullptr;
+    unsigned int pair_epoch = 0;         // a value no earlier launch on these flags used
     int pf_wgs = 0;                      // extra workgroups (lowest ids) that only touch the weight stream ahead of the others; 8 = one per XCD
     unsigned long long* kstamp = nullptr;// diagnostic builds only (-DMTTS_CHAIN_STAMP): 16 phase stamps of workgroup 0
 };
@@ -213,6 +219,10 @@ long chain_stream_frags(int C, int inner, int ch, int n_qkv);
 void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, const float* w1, const float* w2, const float* w_qkv,
                        uint16_t* dst, bool* saturates);
 bool chain_supported(int C, int inner, int n_qkv);
+long chain_stream_frags_pair(int C, int inner, int ch, int n_qkv);       // pair form: fragments per (half, wave)
+void chain_stream_pack_pair(int C, int inner, int ch, int n_qkv, const float* w_out, const float* w1, const float* w2, const float* w_qkv,
+                            uint16_t* dst, bool* saturates);             // dst: 2 * 8 * chain_stream_frags_pair(...) * 512 halves
+bool chain_supported_pair(int C, int inner, int ch, int n_qkv);
 hipError_t launch_tblock_chain(const ChainArgs& a, hipStream_t s);
 static inline double chain_flops(const ChainArgs& a) {
     return 2.0 * double(a.M) * (double(a.C) * a.inner + 8.0 * double(a.C) * a.C + double(a.C) * a.n_qkv);

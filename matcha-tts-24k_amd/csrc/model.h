@@ -43,6 +43,8 @@ struct TBlockW {
     int chain_ch = 0;          // hidden chunk the stream was packed for
     int chain_nqkv = 0;        // width of the q|k|v part (0: none)
     int next = -1;             // index of the block whose q|k|v the chain computes
+    size_t chain_pair = 0;     // the same chain as TWO half streams per wave (kernels.h ChainArgs::pair), offset in floats
+    long chain_pair_frags = 0; // fragments per (half, wave); 0 = not packed
 };
 struct DecW {
     Vec freqs;
@@ -100,6 +102,8 @@ struct mtts_ctx {
     bool chain_on = true;         // transformer blocks' row-local part as one launch (tblock_chain.hip; MTTS_CHAIN=0 at mtts_create disables)
     int chain_ch = 256;           // hidden chunk of the chain's FeedForward at width 384 (MTTS_CHAIN_CH at mtts_create: 128 / 256)
     int chain_qb = 0;             // rows per workgroup (MTTS_CHAIN_QB at mtts_create; 0 = by shape)
+    bool pair_on = true;          // pair form of the chain launch for levels below chain_min_rows (MTTS_CHAIN_PAIR=0 at mtts_create disables)
+    unsigned int pair_epoch = 0;  // flag value of the latest pair launch (unique per launch)
     int chain_min_rows = 6000;    // estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS):
                                   // measured at width 384 -- 10304 rows: 138 vs ~160 us per block; 5152 rows: 100 vs ~92 us (profiles/r03_chain_*)
     mtts::DecW dec;

@@ -93,6 +93,7 @@ static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
     ChainArgs a = a0;
     a.range_flag = c->cur_flag;
     { int qb_unused = 0; chain_plan(a.M, a.ch, a.qb, &qb_unused, &a.pf_wgs); }
+    if (a.pair) a.pf_wgs = chain_prefetch_wgs() ? 16 : 0;      // two per XCD, one per half (the model admits pair grids up to 240 workgroups)
     LAUNCHB(c, 0, chain_flops(a), chain_bytes(a), s, launch_tblock_chain(a, s));
     return 0;
 }
@@ -622,6 +623,13 @@ static int pack_all(mtts_ctx* c, bool dry = false) {
             t.chain_nqkv = nq;
             t.next = nq ? (int)k + 1 : -1;
             t.chain = P.alloc((size_t)t.chain_frags * CHAIN_WAVES * 256);
+            if (c->pair_on && chain_supported_pair(C, inner, ch, nq)) {
+                t.chain_pair_frags = chain_stream_frags_pair(C, inner, ch, nq);
+                t.chain_pair = P.alloc((size_t)t.chain_pair_frags * 2 * CHAIN_WAVES * 256);
+                if (!dry) chain_stream_pack_pair(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
+                                                 nq ? &c->image[D.tb[k + 1].qkv.w] : nullptr, reinterpret_cast<uint16_t*>(&c->image[t.chain_pair]),
+                                                 &c->weights_saturate);
+            }
             t.chain_consts = P.alloc((size_t)18 * C);
             if (!dry) {
                 chain_stream_pack(C, inner, ch, nq, &c->image[t.out.w], &c->image[t.ff1.w], &c->image[t.ff2.w],
@@ -700,6 +708,7 @@ struct DecBufs {
     const int* ne(int l) const { return folded ? nextra[l] : nullptr; }
     const float* kb(int l) const { return folded ? kbias[l] : mask[l]; }
     bool tables = false;
+    unsigned int* pair_flag = nullptr;   // pair form of the chain launch: one flag per (row tile, half), zeroed per call
     bool qkv_ready = false;              // the previous block's chain launch already left this block's q|k|v image in QKV
 };
 
@@ -732,6 +741,7 @@ static int plan_decoder(const mtts_ctx* c, int B, int T, int max_evals, int n_st
     d.Tl.resize(d.nl);
     d.mask.resize(d.nl); d.bufA.resize(d.nl); d.bufB.resize(d.nl); d.skip.resize(d.nl);
     (void)ws.bytes(256);                 // header: the call's range flag (begin_call)
+    d.pair_flag = static_cast<unsigned int*>(ws.bytes(2048));
     d.nrows.resize(d.nl); d.nextra.resize(d.nl); d.kbias.resize(d.nl);
     for (int l = 0; l < d.nl; ++l) {
         d.Tl[l] = T >> l;
@@ -873,7 +883,13 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
         at.B = B; at.T = T; at.H = g.dec_heads; at.D = g.dec_head_dim;
         at.scale = 1.0f / sqrtf((float)g.dec_head_dim); at.mask_mode = 0; at.klen = d.nr(lvl); at.fast16 = c->fast16;
         RET_IF(run_attn(c, at, s));
-        if (chain) {
+        // below that row count: the pair form -- two workgroups of one XCD per 48-row tile, each streaming half of the FeedForward
+        // and of the q|k|v passes -- while all of them (and the prefetchers) are resident at once
+        const int tiles48 = (M + 47) / 48;
+        static const int pair_min = [] { const char* e = getenv("MTTS_CHAIN_PAIR_MIN_ROWS"); return e ? atoi(e) : 3000; }();      // (3864 rows: -0.3..0.5 ms per step, 2576 rows: +0.3; profiles/r03_pair_ab.log)
+        const bool pair = !chain && c->pair_on && t.chain_pair_frags > 0 && d.p16 && !c->half_now && d.pair_flag && M >= pair_min &&
+                          16 * ((tiles48 + 7) / 8) + 16 <= 256 && (emit_stats ? t.chain_nqkv > 0 : true);
+        if (chain || pair) {
             ChainArgs a;
             a.M = M; a.C = C; a.inner = inner;
             a.att16 = ATT16; a.ld_att = 2 * inner;
@@ -890,6 +906,14 @@ static int transformer_block(mtts_ctx* c, DecBufs& d, const TBlockW& t, float* x
             else { a.x_out = d.X16; a.ld_out = 2 * C; }
             a.ch = t.chain_ch;
             { int pf_unused = 0; chain_plan(M, a.ch, c->chain_qb, &a.qb, &pf_unused); }
+            if (pair) {
+                a.pair = 1; a.qb = 48;
+                a.wstream = reinterpret_cast<const _Float16*>(W(c, t.chain_pair)); a.stream_frags = t.chain_pair_frags;
+                a.pair_part = d.FF;              // (the tiled path's hidden image: unused by a chain launch)
+                a.pair_flag = d.pair_flag;
+                a.pair_epoch = ++c->pair_epoch;
+                if (c->pair_epoch == 0) a.pair_epoch = ++c->pair_epoch;
+            }
 #ifdef MTTS_CHAIN_VERIFY
             RET_IF(run_chain_verified(c, a, FF16, s));
 #else
@@ -1297,6 +1321,7 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     { const char* e = getenv("MTTS_CHAIN_CH"); c->chain_ch = (e && atoi(e) == 128) ? 128 : 256; }
     { const char* e = getenv("MTTS_CHAIN_QB"); c->chain_qb = e ? atoi(e) : 0; }
     { const char* e = getenv("MTTS_CHAIN_MIN_ROWS"); if (e) c->chain_min_rows = atoi(e); }
+    { const char* e = getenv("MTTS_CHAIN_PAIR"); c->pair_on = !(e && e[0] == '0'); }
     return c;
 }
 
@@ -1349,7 +1374,7 @@ int mtts_weights_signature(mtts_ctx* c, char* buf, int64_t n) {
     const int v[] = {MTTS_ABI_VERSION, MTTS_IMAGE_REVISION, g.n_feats, g.n_spks, g.spk_emb_dim, g.n_vocab, g.enc_channels, g.enc_filter,
                      g.enc_heads, g.enc_layers, g.enc_kernel, g.prenet_layers, g.prenet_kernel, g.dp_filter, g.dp_kernel, g.dp_layers,
                      g.dec_levels, g.dec_channels[0], g.dec_channels[1], g.dec_channels[2], g.dec_channels[3], g.dec_head_dim, g.dec_heads,
-                     g.dec_n_blocks, g.dec_mid_blocks, c->gemm_terms, c->half16, c->bf16, c->fast16, c->p16_on, c->chain_on, c->chain_ch};
+                     g.dec_n_blocks, g.dec_mid_blocks, c->gemm_terms, c->half16, c->bf16, c->fast16, c->p16_on, c->chain_on, c->chain_ch, c->pair_on};
     std::string sig = "mtts";
     for (int x : v) sig += "-" + std::to_string(x);
     if ((int64_t)sig.size() + 1 > n) { set_error("mtts_weights_signature: buffer too small"); return -1; }
@@ -1424,6 +1449,7 @@ int mtts_decoder_forward(mtts_ctx* c, const float* d_x, const float* d_mask, con
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
     RET_IF(begin_call(c, d_ws, s));
+    if (c->pair_on) HIP_OK(launch_fill_cols(reinterpret_cast<float*>(d.pair_flag), 1, 512, 0, 512, 0.f, s));
     const int nf = c->cfg.n_feats;
     RET_IF(build_frames(c, d, d_mask, nullptr, T, s));
     LAUNCH(c, 2, 0, s, launch_fill_cols(d.xmu, B * T, d.ldx, 2 * nf, d.ldx - 2 * nf, 0.f, s));
@@ -1456,6 +1482,7 @@ static int solve_core(mtts_ctx* c, const float* d_x0, const float* d_mu, const f
     RET_IF(plan_decoder(c, B, T, MAX_EVALS, 2, 4, ws, d));
     if (ws.overflow) { set_error("decoder workspace too small"); return -1; }
     RET_IF(begin_call(c, d_ws, s));
+    if (c->pair_on) HIP_OK(launch_fill_cols(reinterpret_cast<float*>(d.pair_flag), 1, 512, 0, 512, 0.f, s));
     const int nf = c->cfg.n_feats, M = B * T;
     RET_IF(build_frames(c, d, d_mask, d_y_len, T_src, s));
     // state rows: x | mu | zero pad.  z = mu + noise when use_mu_prior (reference flow_matching.py:52-55)
@@ -1875,8 +1902,10 @@ int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w
 }
 int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch) {
     if (!chain_supported(C, inner, n_qkv)) return -1;
-    const int64_t stream = (int64_t)chain_stream_frags(C, inner, ch, n_qkv) * CHAIN_WAVES * 1024;
-    return stream + (int64_t)M * 4 * (inner + 2 * C + n_qkv) + 4 * (int64_t)(2 * n_qkv + 18 * C) + 4096;
+    int64_t stream = (int64_t)chain_stream_frags(C, inner, ch, n_qkv) * CHAIN_WAVES * 1024;
+    if (chain_supported_pair(C, inner, ch, n_qkv)) stream = std::max<int64_t>(stream, (int64_t)chain_stream_frags_pair(C, inner, ch, n_qkv) * 2 * CHAIN_WAVES * 1024);
+    const int64_t pair_scratch = 2 * ((int64_t)M + 64) * C * 4 + 2 * ((int64_t)M / 32 + 2) * 4 + 512;       // partial sums + flags of the pair form
+    return stream + (int64_t)M * 4 * (inner + 2 * C + n_qkv) + 4 * (int64_t)(2 * n_qkv + 18 * C) + 4096 + pair_scratch;
 }
 int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
                       const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
@@ -1885,16 +1914,18 @@ int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int in
     return mtts_tblock_chain_timed(d_att, d_x, M, C, inner, h_w_out, h_b_out, h_w1, h_b1, h_p0, h_p1, h_w2, h_b2, h_w_qkv, h_b_qkv, n_qkv,
                                    d_out_mask, qb, ch, d_x_out, d_qkv_out, d_scratch, stream, 0, nullptr);
 }
-int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
-                            const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
-                            const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
-                            float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms) {
+static int tblock_chain_entry(bool pair, const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                              const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
+                              const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
+                              float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!h_w_qkv) n_qkv = 0;
     if (!chain_supported(C, inner, n_qkv) || !d_x || !h_w1 || !h_w2 || !d_scratch || !d_x_out) { set_error("mtts_tblock_chain: unsupported shape or null buffer"); return -1; }
-    const long frags = chain_stream_frags(C, inner, ch, n_qkv);
-    std::vector<uint16_t> hs((size_t)frags * CHAIN_WAVES * 512);
-    chain_stream_pack(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, hs.data(), nullptr);
+    if (pair && !chain_supported_pair(C, inner, ch, n_qkv)) { set_error("mtts_tblock_chain_pair: unsupported shape"); return -1; }
+    const long frags = pair ? chain_stream_frags_pair(C, inner, ch, n_qkv) : chain_stream_frags(C, inner, ch, n_qkv);
+    std::vector<uint16_t> hs((size_t)frags * (pair ? 2 : 1) * CHAIN_WAVES * 512);
+    if (pair) chain_stream_pack_pair(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, hs.data(), nullptr);
+    else chain_stream_pack(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, hs.data(), nullptr);
     std::vector<float> hc((size_t)18 * C + 2 * (size_t)n_qkv, 0.f);         // wsum1 | b1 | p0 | p1 | b_out | b2 | wsum_qkv | b_qkv
     for (int n = 0; n < 4 * C; ++n) {
         double a = 0.0;
@@ -1918,7 +1949,11 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
     _Float16* att16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * inner * 4;
     _Float16* x16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * C * 4;
     _Float16* xo16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * C * 4;
-    _Float16* q16 = reinterpret_cast<_Float16*>(sc);
+    _Float16* q16 = reinterpret_cast<_Float16*>(sc); sc += (size_t)M * n_qkv * 4;
+    sc = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(sc) + 255) & ~uintptr_t(255));
+    float* d_part = reinterpret_cast<float*>(sc); sc += 2 * ((size_t)M + 64) * C * 4;
+    unsigned int* d_flag = reinterpret_cast<unsigned int*>(sc);
+    if (pair) HIP_OK(hipMemsetAsync(d_flag, 0, 2 * ((size_t)M / 32 + 2) * 4, s));
     HIP_OK(hipMemcpyAsync(d_stream, hs.data(), hs.size() * 2, hipMemcpyHostToDevice, s));
     HIP_OK(hipMemcpyAsync(d_c, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, s));
     HIP_OK(hipStreamSynchronize(s));                      // (the host vectors go out of scope)
@@ -1932,6 +1967,7 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
     a.x_out = xo16; a.ld_out = 2 * C; a.x_out_mask = d_out_mask;
     a.qb = qb; a.ch = ch;
     a.pf_wgs = chain_prefetch_wgs();
+    if (pair) { a.pair = 1; a.pair_part = d_part; a.pair_flag = d_flag; a.pair_epoch = 1; a.pf_wgs = a.pf_wgs ? 16 : 0; }
 #ifdef MTTS_CHAIN_STAMP
     a.kstamp = reinterpret_cast<unsigned long long*>(d_qkv_out);      // (diagnostic build: the stamps land in the q|k|v output buffer)
 #endif
@@ -1945,7 +1981,7 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
         HIP_OK(hipEventCreate(&e0));
         HIP_OK(hipEventCreate(&e1));
         HIP_OK(hipEventRecord(e0, s));
-        for (int i = 0; i < repeat; ++i) HIP_OK(launch_tblock_chain(a, s));
+        for (int i = 0; i < repeat; ++i) { if (pair) a.pair_epoch = 2 + i; HIP_OK(launch_tblock_chain(a, s)); }
         HIP_OK(hipEventRecord(e1, s));
         HIP_OK(hipEventSynchronize(e1));
         HIP_OK(hipEventElapsedTime(h_ms, e0, e1));
@@ -1956,6 +1992,22 @@ int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, 
     HIP_OK(launch_from_p16(xo16, 2 * C, M, C, 2048.0f, d_x_out, C, s));
     if (n_qkv && d_qkv_out) HIP_OK(launch_from_p16(q16, 2 * n_qkv, M, n_qkv, 1.0f, d_qkv_out, n_qkv, s));
     return 0;
+}
+
+int mtts_tblock_chain_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                            const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
+                            const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
+                            float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms) {
+    return tblock_chain_entry(false, d_att, d_x, M, C, inner, h_w_out, h_b_out, h_w1, h_b1, h_p0, h_p1, h_w2, h_b2, h_w_qkv, h_b_qkv, n_qkv,
+                              d_out_mask, qb, ch, d_x_out, d_qkv_out, d_scratch, stream, repeat, h_ms);
+}
+// the pair form of the same launch (two workgroups per row tile; ChainArgs::pair): qb = 48 or 32, at most 120 row tiles
+int mtts_tblock_chain_pair_timed(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
+                                 const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2, const float* h_b2,
+                                 const float* h_w_qkv, const float* h_b_qkv, int n_qkv, const float* d_out_mask, int qb, int ch, float* d_x_out,
+                                 float* d_qkv_out, void* d_scratch, void* stream, int repeat, float* h_ms) {
+    return tblock_chain_entry(true, d_att, d_x, M, C, inner, h_w_out, h_b_out, h_w1, h_b1, h_p0, h_p1, h_w2, h_b2, h_w_qkv, h_b_qkv, n_qkv,
+                              d_out_mask, qb, ch, d_x_out, d_qkv_out, d_scratch, stream, repeat, h_ms);
 }
 
 // ------------------------------------------------------------------------------------------------ measurement

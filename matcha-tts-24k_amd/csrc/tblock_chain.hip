@@ -124,6 +124,44 @@ void chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* w_out, 
     }
 }
 
+// Pair form (ChainArgs::pair): TWO workgroups on one XCD share a row tile.  Both run the out-projection; half h takes the hidden
+// chunks [h NCH/2, (h+1) NCH/2) of the FeedForward and -- after the two FF2 partial sums have been exchanged -- the q|k|v passes
+// [0, ceil(P/2)) or [ceil(P/2), P).  Streams: [half][wave][out-projection | this half's chunks | this half's passes | R padding],
+// every (half, wave) stream padded to the same length (chain_stream_frags_pair).
+long chain_stream_frags_pair(int C, int inner, int ch, int n_qkv) {
+    const int NT = C / 128, NT1 = ch / 128, nch = 4 * C / ch, P = chain_qkv_passes(C, n_qkv);
+    long f = (long)(inner / 32) * 2 * NT;
+    f += (long)(nch / 2) * ((C / 32) * 2 * NT1 + (ch / 32) * 2 * NT);
+    f += (long)((P + 1) / 2) * (C / 32) * 2 * NT;
+    return f + chain_ring(C);
+}
+bool chain_supported_pair(int C, int inner, int ch, int n_qkv) {
+    return chain_supported(C, inner, n_qkv) && inner > 0 && ((4 * C / ch) % 2) == 0;
+}
+void chain_stream_pack_pair(int C, int inner, int ch, int n_qkv, const float* w_out, const float* w1, const float* w2, const float* w_qkv,
+                            uint16_t* dst, bool* saturates) {
+    const int NT = C / 128, NT1 = ch / 128, KG = C / 32, KG2 = ch / 32, NCH = 4 * C / ch;
+    const long per_wave = chain_stream_frags_pair(C, inner, ch, n_qkv);
+    const int passes = chain_qkv_passes(C, n_qkv), p_half = (passes + 1) / 2;
+    std::memset(dst, 0, (size_t)2 * CHAIN_NW * per_wave * 512 * sizeof(uint16_t));
+    for (int h = 0; h < 2; ++h)
+        for (int w = 0; w < CHAIN_NW; ++w) {
+            uint16_t* o = dst + (size_t)(h * CHAIN_NW + w) * per_wave * 512;
+            for (int s = 0; s < inner / 32; ++s)
+                for (int t = 0; t < NT; ++t, o += 1024) put_frag(o, w_out, inner, 16 * (w * NT + t), C, 32 * s, saturates);
+            for (int j = h * (NCH / 2); j < (h + 1) * (NCH / 2); ++j) {
+                for (int s = 0; s < KG; ++s)
+                    for (int t = 0; t < NT1; ++t, o += 1024) put_frag(o, w1, C, j * ch + 16 * (w * NT1 + t), 4 * C, 32 * s, saturates);
+                for (int s = 0; s < KG2; ++s)
+                    for (int t = 0; t < NT; ++t, o += 1024) put_frag(o, w2, 4 * C, 16 * (w * NT + t), C, j * ch + 32 * s, saturates);
+            }
+            for (int ps = h ? p_half : 0; ps < (h ? passes : p_half); ++ps)
+                for (int s = 0; s < KG; ++s)
+                    for (int t = 0; t < NT; ++t, o += 1024)
+                        put_frag(o, w_qkv, C, 16 * (ps * CHAIN_NW * NT + w * NT + t), n_qkv, 32 * s, saturates);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ device
 // diagnostic builds (-DMTTS_CHAIN_STAMP, tools/chain_sweep.py --stamps): s_memtime of wave 0 of workgroup 0 at the phase boundaries
 #ifdef MTTS_CHAIN_STAMP
@@ -180,7 +218,11 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4, swz = (c >> 1) & 7;     // fragment coordinates: row / channel c, k block q
     const int wg = (int)blockIdx.x - p.pf_wgs;                      // the first pf_wgs workgroups only prefetch (below)
-    const int M = p.M, m0 = wg * QB;
+    // pair form: workgroups wg and wg + 8 (the same XCD) share row tile rtile; half = which hidden chunks / q|k|v passes it takes
+    const int pair = p.pair;
+    const int half = pair ? ((wg >> 3) & 1) : 0;
+    const int rtile = pair ? (((wg >> 4) << 3) | (wg & 7)) : wg;
+    const int M = p.M, m0 = rtile * QB;
     const bool has_out = p.inner > 0, has_qkv = p.b_qkv != nullptr;
     const unsigned int lane16 = lane * 16;                          // per-lane byte offset of the stream loads
     CH_STAMP(0);
@@ -192,17 +234,23 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     // window, sleeps or more prefetchers per XCD measured the same) and turns those misses into hits: a computing workgroup's
     // lifetime 117 -> 99 us (32 rows) / 134 -> 116 us (48 rows) on the 100 MHz real-time counter, -0.5..0.7 ms per bench step.
     if (wg < 0) {
-        const char* base = reinterpret_cast<const char*>(p.wstream) + (size_t)wave * (size_t)p.stream_frags * 1024;
         const long bytes = (long)p.stream_frags * 1024;
         unsigned int sink = 0;
+        // (pair form: 16 prefetchers, two per XCD, one per half -- a single one would need longer for both halves' streams than the
+        // computing workgroups live and be the launch's tail)
+        const int pfid = p.pf_wgs + wg, hh = pair ? (pfid >> 3) & 1 : 0;
+        {
+        const char* base = reinterpret_cast<const char*>(p.wstream) + (size_t)(hh * CHAIN_NW + wave) * (size_t)p.stream_frags * 1024;
 #ifdef MTTS_CHAIN_STAMP
         if (p.kstamp && tid == 0) p.kstamp[16 + 2 * ((M + QB - 1) / QB + p.pf_wgs + wg)] = __builtin_amdgcn_s_memtime();
 #endif
-        for (long off = (long)(p.pf_wgs + wg) / 8 * 8192; off < bytes; off += 8192 * ((p.pf_wgs + 7) / 8)) {
+        const int parts = pair ? 1 : (p.pf_wgs + 7) / 8;
+        for (long off = pair ? 0 : (long)(pfid >> 3) * 8192; off < bytes; off += 8192L * parts) {
             const long o = off + lane * 128;                        // (several prefetch workgroups per XCD interleave their 8 KiB pieces)
             const unsigned int ob = (unsigned int)(o < bytes ? o : bytes - 128);
             asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(ob), "s"(base));
             asm volatile("s_waitcnt vmcnt(8)");
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)");
         asm volatile("" : "+v"(sink));
@@ -227,7 +275,8 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
 
     // ---- the wave's weight stream through a register ring: fragment f of the current position sits in ring[f % R].
     // wpos: (uniform) address of the fragment that is the current position.
-    const char* wpos = reinterpret_cast<const char*>(p.wstream) + (size_t)wave * (size_t)p.stream_frags * 1024;
+    if (wg >= 0 && m0 >= M) return;                                 // (pair form: the grid is rounded up to whole groups of 16)
+    const char* wpos = reinterpret_cast<const char*>(p.wstream) + (size_t)(half * CHAIN_NW + wave) * (size_t)p.stream_frags * 1024;
     u32x4 ring[R];
 #pragma unroll
     for (int i = 0; i < R; i += 2) CH_LOAD2(ring[i], ring[i + 1], lane16, wpos + i * 1024);
@@ -433,7 +482,9 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
     zero_acc();
     {
         constexpr int F1 = KG * F1S;                      // fragments of a chunk's FF1 part
-        for (int j = 0; j < K::NCH; ++j) {
+        const int nch = pair ? K::NCH / 2 : K::NCH, j0 = half * (K::NCH / 2);
+        for (int jj = 0; jj < nch; ++jj) {
+            const int j = j0 + jj;
             f32x4 a1[NT1][MT], a1x[NT1][MT];
 #pragma unroll
             for (int t = 0; t < NT1; ++t)
@@ -460,7 +511,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
                 for (int t = 0; t < NT1; ++t) refill(fb + 2 * t, s * F1S + 2 * t);
             }
             ring_drain();
-            if (j < 2) CH_STAMP(4 + 3 * j);
+            if (jj < 2) CH_STAMP(4 + 3 * jj);
             // ---- LayerNorm after the product, SnakeBeta, split -> hidden chunk image in HT
             float nmr[MT], rstd[MT];                      // this lane's rows: -mean rstd, rstd
 #pragma unroll
@@ -487,26 +538,86 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
                 }
             }
             __syncthreads();
-            if (j < 2) CH_STAMP(5 + 3 * j);
-            if (j == 0) CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4, HT, K::HT_BYTES);
+            if (jj < 2) CH_STAMP(5 + 3 * jj);
+            if (jj == 0) CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4, HT, K::HT_BYTES);
             // ---- FF2: out^T += W2[:, chunk] . hidden chunk^T
 #pragma unroll
             for (int s = 0; s < KG2; ++s) step_wide((F1 + s * FW) % R, HT, s, F1 + s * FW, 0);
             ring_drain();
             wpos += (F1 + KG2 * FW) * 1024;
             __syncthreads();                              // the hidden chunk may be overwritten
-            if (j < 2) CH_STAMP(6 + 3 * j);
+            if (jj < 2) CH_STAMP(6 + 3 * jj);
         }
     }
     CH_STAMP(10);
-    rows_to_xt(CT + 17 * C);
+    if (pair) {
+        // ---- the two halves' FF2 partial sums meet: each workgroup publishes its own (fp32, global scratch), waits for the other's
+        // flag and forms x2 = ((x1 + b2) + P0) + P1 -- the same expression in both, so both hold the same bits.  Publication:
+        // every wave's stores drained, barrier, then ONE lane releases at agent scope and stores the flag; the reader polls relaxed,
+        // acquires once, and the barrier behind it orders every lane's loads (MI355X_MICROARCH.md, handoff recipe).  Both
+        // workgroups are resident (the launcher refuses pair grids beyond one round of the chip); the poll is bounded all the same.
+        float* const mine = p.pair_part + (size_t)(rtile * 2 + half) * QB * C;
+        const float* const other = p.pair_part + (size_t)(rtile * 2 + (half ^ 1)) * QB * C;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ch = 16 * (wave * NT + t) + 4 * q;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][i][e] = acc[t][i][e] + accx[t][i][e] * (1.0f / F16_RES_SCALE);
+                // write-through stores (sc1): the partial leaves the L2 at once, so the release below finds nothing dirty to write back
+                // (a release with ~2 MB of freshly dirtied lines per XCD, issued by 27 workgroups at once, cost tens of microseconds)
+                float* dst = mine + (size_t)(16 * i + c) * C + ch;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[t][i]) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.pair_flag + rtile * 2 + half, p.pair_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int budget = 1 << 21;
+            while (__hip_atomic_load(p.pair_flag + rtile * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_epoch && --budget > 0)
+                __builtin_amdgcn_s_sleep(8);
+            if (budget <= 0 && p.range_flag) atomicOr(p.range_flag + 1, 1u);      // the partner never showed up: the call's results are void
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const float* bias = CT + 17 * C;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ch = 16 * (wave * NT + t) + 4 * q;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(other + (size_t)(16 * i + c) * C + ch);
+                const f32x4 p0 = half ? o4 : acc[t][i], p1 = half ? acc[t][i] : o4;
+                char* ph = XT + img_off(ch, i, 0);
+                char* pl = XT + img_off(ch, i, 1);
+                const f16x4 rh = *reinterpret_cast<const f16x4*>(ph), rl = *reinterpret_cast<const f16x4*>(pl);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = ((((float)rh[e] + (float)rl[e] * (1.0f / F16_RES_SCALE)) + b4[e]) + p0[e]) + p1[e];
+                u32x2 hw, lw;
+                split4(v, F16_RES_SCALE, hw, lw, rmax);
+                *reinterpret_cast<u32x2*>(ph) = hw;
+                *reinterpret_cast<u32x2*>(pl) = lw;
+            }
+        }
+    } else {
+        rows_to_xt(CT + 17 * C);
+    }
     __syncthreads();
     CH_DUMP(2 * K::XT_BYTES + K::CT_FLOATS * 4 + 2 * QB * 4 + K::HT_BYTES, XT, K::XT_BYTES);
 
     // ---- the block's output rows: LDS image -> global image, whole 16-byte chunks, coalesced
     {
         constexpr int CPR = C / 4;                        // 16-byte chunks per row
-        for (int idx = tid; idx < QB * CPR; idx += 64 * CHAIN_NW) {
+        const int r_lo = pair ? half * (QB / 2) : 0, r_hi = pair ? (half + 1) * (QB / 2) : QB;      // (pair form: each half stores half the rows)
+        for (int idx = tid + r_lo * CPR; idx < r_hi * CPR; idx += 64 * CHAIN_NW) {
             const int row = idx / CPR, cc = idx - row * CPR;
             if (m0 + row < M) {
                 f16x8 v = *reinterpret_cast<const f16x8*>(XT + (cc >> 3) * (QB * 128) + row * 128 + (((cc & 7) ^ ((row >> 1) & 7)) * 16));
@@ -527,7 +638,9 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         const int ntiles = p.n_qkv >> 4;
         const int passes = (ntiles + CHAIN_NW * NT - 1) / (CHAIN_NW * NT);
         const bool all_stores = m0 + QB <= M;             // (uniform) no row of the tile is past the end
-        for (int ps = 0; ps < passes; ++ps) {
+        const int p_half = (passes + 1) / 2;
+        const int ps0 = pair ? (half ? p_half : 0) : 0, ps1 = pair ? (half ? passes : p_half) : passes;
+        for (int ps = ps0; ps < ps1; ++ps) {
             zero_acc();
 #pragma unroll
             for (int s = 0; s < KG; ++s) step_wide((s * FW) % R, XT, s, s * FW, 0);
@@ -607,7 +720,10 @@ static hipError_t launch_chain_shape(const ChainArgs& a, hipStream_t s) {
     }
     static const std::string tag = "tblock_chain_kernel<" + std::to_string(C) + ", " + std::to_string(QB) + ", " + std::to_string(CH) + ">";
     g_kernel_tag = tag.c_str();
-    hipLaunchKernelGGL(kern, dim3((a.M + QB - 1) / QB + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
+    const int tiles = (a.M + QB - 1) / QB;
+    const int wgs = a.pair ? 16 * ((tiles + 7) / 8) : tiles;
+    if (a.pair && (wgs + a.pf_wgs > 256 || (a.pf_wgs != 0 && a.pf_wgs != 16))) return hipErrorInvalidValue;      // both halves of every pair must be resident at once
+    hipLaunchKernelGGL(kern, dim3(wgs + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(64 * CHAIN_NW), K::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -618,7 +734,10 @@ hipError_t launch_tblock_chain(const ChainArgs& a, hipStream_t s) {
     if (a.inner && (!a.att16 || a.ld_att < 2 * a.inner || (a.ld_att & 7))) return hipErrorInvalidValue;
     if (a.b_qkv && (!a.wsum_qkv || !a.qkv16 || a.n_qkv <= 0 || a.ld_qkv < 2 * a.n_qkv || (a.ld_qkv & 3))) return hipErrorInvalidValue;
     if (a.ld_x < 2 * a.C || (a.ld_x & 7) || a.ld_out < 2 * a.C || (a.ld_out & 7)) return hipErrorInvalidValue;
-    if (a.stream_frags != chain_stream_frags(a.C, a.inner, a.ch, a.b_qkv ? a.n_qkv : 0)) return hipErrorInvalidValue;
+    if (a.pair) {
+        if (!chain_supported_pair(a.C, a.inner, a.ch, a.n_qkv) || !a.pair_part || !a.pair_flag || a.pair_epoch == 0 || (a.pf_wgs & 7)) return hipErrorInvalidValue;
+        if (a.stream_frags != chain_stream_frags_pair(a.C, a.inner, a.ch, a.b_qkv ? a.n_qkv : 0)) return hipErrorInvalidValue;
+    } else if (a.stream_frags != chain_stream_frags(a.C, a.inner, a.ch, a.b_qkv ? a.n_qkv : 0)) return hipErrorInvalidValue;
     if (a.C == 384) {
         if (a.ch == 128 && a.qb == 64) return launch_chain_shape<384, 64, 128>(a, s);
         if (a.ch == 128 && a.qb == 32) return launch_chain_shape<384, 32, 128>(a, s);

@@ -117,7 +117,11 @@ class MatchaTTSInfer(nn.Module):
         out = None
         if not saturated:
             out = self._synthesise(*args)
-            saturated = bool(hip.range_flags().any().item())
+            flags = torch.cat([hip.range_flags(), hip.pair_timeouts()]).tolist()       # one read, one synchronisation
+            if flags[2]:
+                raise RuntimeError("matcha-tts-24k_amd: a pair-form chain launch timed out waiting for its partner workgroup (another "
+                                   "kernel held CUs during the launch?); set MTTS_CHAIN_PAIR=0")
+            saturated = bool(flags[0] or flags[1])
         if not saturated:
             return out
         if self.range_policy == "raise" or sync_max is not None:     # (a rank-local rerun would repeat sync_max's collective)

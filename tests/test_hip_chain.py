@@ -134,3 +134,42 @@ def test_prefetch_workgroups_do_not_change_results(hip):
         assert out.returncode == 0, out.stderr[-2000:]
         hashes[pf] = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("HASH")][0]
     assert len(set(hashes.values())) == 1, hashes
+
+
+PAIR_CASES = [
+    # M, C, inner, n_qkv, qb, ch
+    (500, 384, 384, 1152, 48, 256),       # 11 row tiles -> 32 workgroups (two groups of 16, the second partly idle)
+    (130, 384, 384, 1152, 32, 256),
+    (300, 384, 384, 0, 48, 256),          # last block of a run: no q|k|v
+    (90, 256, 192, 576, 64, 128),         # 8 hidden chunks, q|k|v width that does not fill its last pass
+    (70, 128, 128, 384, 32, 128),
+]
+
+
+@pytest.mark.parametrize("M,C,inner,n_qkv,qb,ch", PAIR_CASES)
+def test_chain_pair_form_vs_fp64(hip, M, C, inner, n_qkv, qb, ch):
+    """The pair form (two workgroups of one XCD per row tile, FF2 partial sums exchanged through the L2): same bar as the
+    single-workgroup form, bitwise repeatable, and equal to that form up to the order of one addition per element."""
+    case = make_case(M, C, inner, n_qkv, seed=300 + M)
+    x1, x2, qkv = chain_ref(*case)
+    dev = torch.device("cuda")
+    args = dict(w_qkv=case[10], b_qkv=case[11], qb=qb, ch=ch)
+    x_out, qkv_out = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], pair=True, **args)
+    close(x_out, x2, 2e-5, "x_out")
+    if n_qkv:
+        close(qkv_out, qkv, 3e-5, "qkv")
+    again, q_again = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], pair=True, **args)
+    assert torch.equal(again, x_out) and (not n_qkv or torch.equal(q_again, qkv_out))
+    single, q_single = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], **args)
+    assert (single - x_out).abs().max().item() <= 4e-6 * max(1.0, x2.abs().max().item())
+
+
+def test_chain_pair_form_masked_rows(hip):
+    M, C = 200, 384
+    case = make_case(M, C, 384, 0, seed=11)
+    dev = torch.device("cuda")
+    mask = (torch.arange(M) % 3 != 0).float()
+    plain, _ = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], qb=48, ch=256, pair=True)
+    masked, _ = hip.tblock_chain(case[0].to(dev), case[1].to(dev), *case[2:10], out_mask=mask.to(dev), qb=48, ch=256, pair=True)
+    keep = mask.bool().to(dev)
+    assert torch.equal(masked[keep], plain[keep]) and masked[~keep].abs().max().item() == 0.0

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: one batch of B utterances as S independent sub-batches on S HIP streams (utterances are independent, so the
 sub-batches' kernels can fill each other's ramp-up / tail / inter-kernel gaps).  python tools/stream_split.py [--batch 32]"""
+import os
+os.environ.setdefault("MTTS_CHAIN_PAIR", "0")       # several contexts share the card here: a pair-form chain launch needs the chip to itself
 import argparse
 import importlib
 import sys
