@@ -236,6 +236,10 @@ int mtts_attention_p16(const float* d_qkv, const float* d_mask, int B, int T, in
  * halves with lane (r = lane & 15, q = lane >> 4) holding panel row n0 + r, columns k0 + 8 q .. + 7 (the A operand of
  * v_mfma_f32_16x16x32_f16).  h_dst: mtts_chain_stream_frags(...) * 8 * 512 halves. */
 int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv);
+/* Threading / sharing note for the estimator entry points: between 3000 and 6000 estimator rows the transformer blocks run the PAIR
+ * form of the chain launch (below), in which two workgroups wait for each other inside the kernel.  It assumes the launch has the GPU
+ * to itself (one stream per device at a time); a process that shares a device between several contexts sets MTTS_CHAIN_PAIR=0.  A
+ * workgroup whose partner does not arrive within ~0.5 s gives up and sets the second word of the workspace header. */
 /* The model's launch plan of a chain launch over M rows (hidden chunk ch = 128 / 256): rows per workgroup and the number of
  * prefetch workgroups (MTTS_CHAIN_PF, default 8).  Host arithmetic only. */
 int mtts_chain_plan(int M, int ch, int* qb, int* prefetch_wgs);

@@ -165,11 +165,16 @@ void chain_stream_pack_pair(int C, int inner, int ch, int n_qkv, const float* w_
 // ------------------------------------------------------------------------------------------------ device
 // diagnostic builds (-DMTTS_CHAIN_STAMP, tools/chain_sweep.py --stamps): s_memtime of wave 0 of workgroup 0 at the phase boundaries
 #ifdef MTTS_CHAIN_STAMP
-#define CH_STAMP(i) do { if (p.kstamp && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (wg == 0) p.kstamp[i] = t_; \
+#define CH_STAMP(i) do { if (p.kstamp && tid == 0 && wg >= 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (wg == 0) p.kstamp[i] = t_; \
         if ((i) == 0) p.kstamp[16 + 2 * wg] = t_; if ((i) == 12) p.kstamp[17 + 2 * wg] = t_; \
         if (wg == 0 && ((i) == 0 || (i) == 12)) p.kstamp[16 + 2 * ((M + QB - 1) / QB + p.pf_wgs) + ((i) == 12)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define CH_STAMP(i) do { } while (0)
+#endif
+#ifdef MTTS_CHAIN_STAMP
+#define CH_XSTAMP(k) do { if (p.kstamp && tid == 0 && wg == 0) p.kstamp[4000 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)   /* inside the pair exchange */
+#else
+#define CH_XSTAMP(k) do { } while (0)
 #endif
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -556,8 +561,11 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         // every wave's stores drained, barrier, then ONE lane releases at agent scope and stores the flag; the reader polls relaxed,
         // acquires once, and the barrier behind it orders every lane's loads (MI355X_MICROARCH.md, handoff recipe).  Both
         // workgroups are resident (the launcher refuses pair grids beyond one round of the chip); the poll is bounded all the same.
+        // (lane-native layout [tile][half][t][i][thread] of 16-byte pieces: a wave instruction writes / reads 1 KiB of whole lines;
+        // the partner's thread of the same index owns the same element)
         float* const mine = p.pair_part + (size_t)(rtile * 2 + half) * QB * C;
         const float* const other = p.pair_part + (size_t)(rtile * 2 + (half ^ 1)) * QB * C;
+        auto slot = [&](int t, int i) { return (size_t)((t * MT + i) * (64 * CHAIN_NW) + tid) * 4; };
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int ch = 16 * (wave * NT + t) + 4 * q;
@@ -565,26 +573,33 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][i][e] = acc[t][i][e] + accx[t][i][e] * (1.0f / F16_RES_SCALE);
-                // write-through stores (sc1): the partial leaves the L2 at once, so the release below finds nothing dirty to write back
-                // (a release with ~2 MB of freshly dirtied lines per XCD, issued by 27 workgroups at once, cost tens of microseconds)
-                float* dst = mine + (size_t)(16 * i + c) * C + ch;
+                // write-through stores (sc1): the partial leaves the L2 at once and the release below finds nothing dirty to write back
+                // (plain stores measured slower: 13k instead of 3.6k cycles until they had landed, 27k instead of 23k for the exchange)
+                float* dst = mine + slot(t, i);
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[t][i]) : "memory");
             }
         }
+        CH_XSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CH_XSTAMP(1);
         __syncthreads();
+        CH_XSTAMP(2);
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CH_XSTAMP(3);
             __hip_atomic_store(p.pair_flag + rtile * 2 + half, p.pair_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int budget = 1 << 21;
             while (__hip_atomic_load(p.pair_flag + rtile * 2 + (half ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_epoch && --budget > 0)
                 __builtin_amdgcn_s_sleep(8);
+            CH_XSTAMP(4);
             if (budget <= 0 && p.range_flag) atomicOr(p.range_flag + 1, 1u);      // the partner never showed up: the call's results are void
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CH_XSTAMP(5);
         }
         __syncthreads();
+        CH_XSTAMP(6);
         const float* bias = CT + 17 * C;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const f32x4 o4 = *reinterpret_cast<const f32x4*>(other + (size_t)(16 * i + c) * C + ch);
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(other + slot(t, i));
                 const f32x4 p0 = half ? o4 : acc[t][i], p1 = half ? acc[t][i] : o4;
                 char* ph = XT + img_off(ch, i, 0);
                 char* pl = XT + img_off(ch, i, 1);
@@ -607,6 +622,7 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
                 *reinterpret_cast<u32x2*>(pl) = lw;
             }
         }
+        CH_XSTAMP(7);
     } else {
         rows_to_xt(CT + 17 * C);
     }

@@ -21,16 +21,21 @@ def main():
              p1=1.0 / (torch.exp(r(4 * C, sc=0.2)) + 1e-9), w2=r(C, 4 * C, sc=(4 * C) ** -0.5), b2=r(C))
     wq, bq = r(nq, C, sc=C ** -0.5), r(nq)
     for cfg in sys.argv[1:] or ["64:128:64", "64:128:10304", "32:128:5152", "48:256:10304"]:
-        qb, ch, M = (int(v) for v in cfg.split(":"))
+        pair = cfg.endswith(":pair")                           # "48:256:5152:pair": the pair form (two workgroups per row tile)
+        qb, ch, M = (int(v) for v in cfg.split(":")[:3])
         att, x = r(M, inner).cuda(), (r(M, C) * 2 + 0.3).cuda()
         for rep in range(2):                                   # second call: caches warm
-            _, q = hip.tblock_chain(att, x, w["w_out"], w["b_out"], w["w1"], w["b1"], w["p0"], w["p1"], w["w2"], w["b2"], w_qkv=wq, b_qkv=bq, qb=qb, ch=ch)
+            _, q = hip.tblock_chain(att, x, w["w_out"], w["b_out"], w["w1"], w["b1"], w["p0"], w["p1"], w["w2"], w["b2"], w_qkv=wq, b_qkv=bq, qb=qb, ch=ch, pair=pair)
         st = q.view(-1).view(torch.int64)[:16].cpu().tolist()
-        print(f"== qb {qb} ch {ch} rows {M} ({(M + qb - 1) // qb} workgroups): total {st[12] - st[0]} cycles")
+        print(f"== qb {qb} ch {ch} rows {M}{' PAIR form' if pair else ''} ({(M + qb - 1) // qb} row tiles): total {st[12] - st[0]} cycles")
         prev = st[0]
         for i in range(1, 12):
             print(f"   {st[i] - prev:8d}  {NAMES[i]}")
             prev = st[i]
+        if pair:
+            xs = q.view(-1).view(torch.int64)[4000:4008].cpu().tolist()
+            names = ["partial stores issued", "stores landed (vmcnt 0)", "barrier", "release fence", "partner's flag seen", "acquire fence", "barrier", "partner's partial read, x2 formed"]
+            print("   inside the exchange (cycles since its start):", "; ".join(f"{n} {xs[k] - xs[0]}" for k, n in enumerate(names) if k))
         nwg = (M + qb - 1) // qb
         allst = q.view(-1).view(torch.int64)[16:16 + 2 * nwg].cpu().view(nwg, 2)
         t0 = int(allst[:, 0].min())

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--cfg", default="64:128,32:128,48:256,32:256")
     ap.add_argument("--no-qkv", action="store_true")
     ap.add_argument("--repeat", type=int, default=20)
+    ap.add_argument("--pair", action="store_true", help="the pair form (two workgroups per row tile)")
     a = ap.parse_args()
     C, inner, nq = 384, 384, 0 if a.no_qkv else 1152
     g = torch.Generator().manual_seed(1)
@@ -30,7 +31,7 @@ def main():
         qb, ch = (int(v) for v in cfg.split(":"))
         for M in (int(v) for v in a.rows.split(",")):
             att, x = r(M, inner).cuda(), (r(M, C) * 2 + 0.3).cuda()
-            _, _, ms = hip.tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=wq, b_qkv=bq, qb=qb, ch=ch, repeat=a.repeat)
+            _, _, ms = hip.tblock_chain(att, x, w_out, b_out, w1, b1, p0, p1, w2, b2, w_qkv=wq, b_qkv=bq, qb=qb, ch=ch, repeat=a.repeat, pair=a.pair)
             wbytes = 4.0 * (C * inner + 8 * C * C + C * nq)
             print(f"{M:6d} {qb:3d} {ch:4d} {(M + qb - 1) // qb:5d} {ms * 1e3:8.1f} {flop_row * M / ms / 1e9:7.1f} {wbytes / ms / 1e6:22.1f}")
 
