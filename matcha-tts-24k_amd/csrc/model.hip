@@ -215,6 +215,7 @@ static int run_chain_verified(mtts_ctx* c, const ChainArgs& a0, _Float16* scratc
     }
 #endif
     RET_IF(run_chain(c, a, s));
+    if (a.pair) return 0;            // (a pair launch's flags carry one epoch: it cannot simply be executed again)
     if (a.x_out == a.x16 || g_verify_n + 2 > VERIFY_SLOTS) return 0;
     ChainArgs b = a, b3 = a;
     b.x_out = scratch;
