@@ -245,6 +245,11 @@ int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv);
 int mtts_chain_plan(int M, int ch, int* qb, int* prefetch_wgs);
 int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
                            const float* h_w_qkv, uint16_t* h_dst);
+/* pair form (below): fragments per (half, wave) and the packing of the 2 x 8 streams, [half][wave][fragment][64 lanes][8 halves];
+ * h_dst: 2 * 8 * mtts_chain_stream_frags_pair(...) * 512 halves.  Host only. */
+int64_t mtts_chain_stream_frags_pair(int C, int inner, int ch, int n_qkv);
+int mtts_chain_stream_pack_pair(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
+                                const float* h_w_qkv, uint16_t* h_dst);
 int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch);
 int mtts_tblock_chain(const float* d_att, const float* d_x, int M, int C, int inner, const float* h_w_out, const float* h_b_out,
                       const float* h_w1, const float* h_b1, const float* h_p0, const float* h_p1, const float* h_w2,

@@ -154,6 +154,8 @@ def load() -> C.CDLL:
         "mtts_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp, vp]),
         "mtts_chain_stream_frags": (i64, [i32, i32, i32, i32]),
         "mtts_chain_plan": (i32, [i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mtts_chain_stream_frags_pair": (i64, [i32, i32, i32, i32]),
+        "mtts_chain_stream_pack_pair": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "mtts_chain_stream_pack": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "mtts_tblock_chain_scratch_bytes": (i64, [i32, i32, i32, i32, i32]),
         "mtts_tblock_chain": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]),

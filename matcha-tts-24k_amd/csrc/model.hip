@@ -1901,6 +1901,20 @@ int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w
     chain_stream_pack(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, h_dst, nullptr);
     return 0;
 }
+// pair form: fragments per (half, wave), and the packing of the 2 x 8 streams (host only)
+int64_t mtts_chain_stream_frags_pair(int C, int inner, int ch, int n_qkv) {
+    if (!chain_supported_pair(C, inner, ch, n_qkv) || (ch != 128 && ch != 256)) { set_error("mtts_chain_stream_frags_pair: unsupported shape"); return -1; }
+    return chain_stream_frags_pair(C, inner, ch, n_qkv);
+}
+int mtts_chain_stream_pack_pair(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
+                                const float* h_w_qkv, uint16_t* h_dst) {
+    if (!chain_supported_pair(C, inner, ch, n_qkv) || (ch != 128 && ch != 256) || !h_w_out || !h_w1 || !h_w2 || !h_dst || (n_qkv && !h_w_qkv)) {
+        set_error("mtts_chain_stream_pack_pair: unsupported shape or null panel");
+        return -1;
+    }
+    chain_stream_pack_pair(C, inner, ch, n_qkv, h_w_out, h_w1, h_w2, h_w_qkv, h_dst, nullptr);
+    return 0;
+}
 int64_t mtts_tblock_chain_scratch_bytes(int M, int C, int inner, int n_qkv, int ch) {
     if (!chain_supported(C, inner, n_qkv)) return -1;
     int64_t stream = (int64_t)chain_stream_frags(C, inner, ch, n_qkv) * CHAIN_WAVES * 1024;

@@ -568,7 +568,6 @@ __global__ __launch_bounds__(64 * CHAIN_NW, 1) void tblock_chain_kernel(const Ch
         auto slot = [&](int t, int i) { return (size_t)((t * MT + i) * (64 * CHAIN_NW) + tid) * 4; };
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int ch = 16 * (wave * NT + t) + 4 * q;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll

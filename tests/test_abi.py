@@ -189,3 +189,62 @@ def test_chain_launch_plan_keeps_grids_to_one_round(lib):
     assert plan(64 * 322) == (48, 8)              # several rounds anyway
     assert plan(5152, ch=128) == (32, 8) and plan(10304, ch=128) == (64, 8)
     assert lib.mtts_chain_plan(0, 256, None, None) != 0
+
+
+@pytest.mark.parametrize("C,inner,ch,n_qkv", [(384, 384, 256, 1152), (384, 384, 256, 0), (256, 192, 128, 576), (128, 128, 128, 384)])
+def test_chain_pair_stream_layout(lib, C, inner, ch, n_qkv):
+    """The pair form's streams (csrc/tblock_chain.hip chain_stream_pack_pair), walked as the kernel walks them: both halves carry the
+    whole out-projection, half h the hidden chunks [h NCH/2, (h+1) NCH/2) and the q|k|v passes [0, ceil(P/2)) / [ceil(P/2), P); every
+    (half, wave) stream has the same length, ends in zeros, and together the two halves rebuild every panel."""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    w_out = rng.standard_normal((C, inner)).astype(np.float32)
+    w1 = rng.standard_normal((4 * C, C)).astype(np.float32)
+    w2 = rng.standard_normal((C, 4 * C)).astype(np.float32)
+    w_qkv = rng.standard_normal((n_qkv, C)).astype(np.float32) if n_qkv else None
+    frags = lib.mtts_chain_stream_frags_pair(C, inner, ch, n_qkv)
+    assert frags > 0
+    dst = np.full(2 * frags * 8 * 512 + 64, 0x7E00, dtype=np.uint16)
+    assert lib.mtts_chain_stream_pack_pair(C, inner, ch, n_qkv, w_out.ctypes.data, w1.ctypes.data, w2.ctypes.data,
+                                           w_qkv.ctypes.data if n_qkv else None, dst.ctypes.data) == 0
+    assert (dst[-64:] == 0x7E00).all()
+    stream = dst[:-64].view(np.float16).reshape(2, 8, frags, 64, 8).astype(np.float64)
+    NT, NT1, KG, KG2, R, NCH = C // 128, ch // 128, C // 32, ch // 32, (24 if C == 384 else 8), 4 * C // ch
+    lane = np.arange(64)
+    r, q = lane & 15, lane >> 4
+    got = {"w1": np.zeros_like(w1, dtype=np.float64), "w2": np.zeros_like(w2, dtype=np.float64), "qkv": np.zeros((n_qkv, C))}
+
+    def take(panel, wave_frags, pos, n0, k0, n_valid):
+        val = wave_frags[pos] + wave_frags[pos + 1] / 2048.0
+        for j in range(8):
+            rows = n0 + r
+            ok = rows < n_valid
+            panel[rows[ok], (k0 + 8 * q + j)[ok]] = val[ok, j]
+        return pos + 2
+
+    passes = -(-(n_qkv // 16) // (8 * NT)) if n_qkv else 0
+    p_half = (passes + 1) // 2
+    for h in range(2):
+        out = np.zeros_like(w_out, dtype=np.float64)
+        for w in range(8):
+            f, pos = stream[h, w], 0
+            for s in range(inner // 32):
+                for t in range(NT):
+                    pos = take(out, f, pos, 16 * (w * NT + t), 32 * s, C)
+            assert pos % (8 if C != 384 else 12) == 0
+            for j in range(h * NCH // 2, (h + 1) * NCH // 2):
+                for s in range(KG):
+                    for t in range(NT1):
+                        pos = take(got["w1"], f, pos, j * ch + 16 * (w * NT1 + t), 32 * s, 4 * C)
+                for s in range(KG2):
+                    for t in range(NT):
+                        pos = take(got["w2"], f, pos, 16 * (w * NT + t), j * ch + 32 * s, C)
+            for ps in range(p_half if h else 0, passes if h else p_half):
+                for s in range(KG):
+                    for t in range(NT):
+                        pos = take(got["qkv"], f, pos, 16 * (ps * 8 * NT + w * NT + t), 32 * s, n_qkv)
+            assert pos + R <= frags and (f[pos:] == 0).all()
+        assert np.abs(out - w_out).max() <= 2.0 ** -21 * np.abs(w_out).max()
+    for name, ref in (("w1", w1), ("w2", w2), ("qkv", w_qkv)):
+        if ref is not None and ref.size:
+            assert np.abs(got[name] - ref).max() <= 2.0 ** -21 * np.abs(ref).max(), name
