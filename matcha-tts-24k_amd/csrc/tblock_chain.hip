@@ -24,6 +24,11 @@
 //     holds 4 consecutive channels of one row, so every LDS / global store of an epilogue is 8 bytes of one image line;
 //   * LayerNorm statistics are taken from the LDS tile (one wave per row, two passes), applied after the product as
 //     rstd (x.W'^T - mean rowsum(W')) + b' exactly as gemm_p16.hip does.
+//   * what bounds it is the CU's line-fill rate (~37 B/clk): every workgroup pulls the block's whole fragment stream (7 MB) through
+//     its CU.  Two answers: prefetch workgroups -- one per XCD does nothing but touch the stream just ahead of
+//     the others, so their loads hit the L2 -- and, where the rows of a level do not fill the chip with one workgroup per tile, the
+//     PAIR form: two workgroups of one XCD share a tile, each streams half of the FeedForward and of the q|k|v passes, and the two
+//     FF2 partial sums meet through global memory behind an agent-scope release / acquire.
 // Arithmetic = gemm_p16.hip MODE 0: x = h + l / 2^11, products h.h + (h.l + l.h) / 2^11, fp32 accumulation.
 #include "kernels.h"
 #include "device_utils.h"
