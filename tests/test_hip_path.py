@@ -548,6 +548,30 @@ def test_per_request_padding_on_folded_rows(tiny, prod, synthetic, dev):
         assert maxabs(folded["mel"], full["mel"]) < 1e-4
 
 
+def test_graph_replay_with_both_chain_forms(prod, synthetic, dev):
+    """B = 20, 128 tokens (6440 / 3220 estimator rows: the single-workgroup chain at the full-length level, the PAIR form at the
+    half-length level) forced onto a captured HIP graph: the pair launches' flag values are baked into the graph, so every replay
+    depends on the flags being zeroed inside it -- replay twice, compare with the direct launches and bit for bit with each other."""
+    hp, sd, model = prod
+    dec = model.decoder
+    keep = dec.graph_mode, dec.solver, dec.graph_max_rows
+    x, x_len, _ = synthetic.make_inputs(hp, 20, 128, seed=77)
+    z = synthetic.cpu_noise((20, 100, 640)).to(dev)
+    try:
+        dec.solver = "euler"
+        dec.graph_mode = "0"
+        direct = model.synthesise(x.to(dev), x_len.to(dev), 3, speaker=0, z=z)["mel"]
+        dec.graph_mode = "1"
+        dec.graph_max_rows = 1 << 20
+        first = model.synthesise(x.to(dev), x_len.to(dev), 3, speaker=0, z=z)["mel"]
+        second = model.synthesise(x.to(dev), x_len.to(dev), 3, speaker=0, z=z)["mel"]
+        assert torch.equal(first, second)
+        assert maxabs(first, direct) < 1e-4
+    finally:
+        dec.graph_mode, dec.solver, dec.graph_max_rows = keep
+        dec._graphs.clear()
+
+
 # ------------------------------------------------------------------------------------------------ HIP graphs (small batches)
 def test_graph_replay_equals_direct_launches(prod, tiny, synthetic, dev):
     """Launch-bound sizes run the ODE solve as one captured HIP graph per (batch, row bucket, solver, steps) (modules.CFM.
