@@ -241,7 +241,7 @@ int64_t mtts_chain_stream_frags(int C, int inner, int ch, int n_qkv);
  * to itself (one stream per device at a time); a process that shares a device between several contexts sets MTTS_CHAIN_PAIR=0.  A
  * workgroup whose partner does not arrive within ~0.5 s gives up and sets the second word of the workspace header. */
 /* The model's launch plan of a chain launch over M rows (hidden chunk ch = 128 / 256): rows per workgroup and the number of
- * prefetch workgroups (MTTS_CHAIN_PF, default 8).  Host arithmetic only. */
+ * prefetch workgroups (MTTS_CHAIN_PF, default 16).  Host arithmetic only. */
 int mtts_chain_plan(int M, int ch, int* qb, int* prefetch_wgs);
 int mtts_chain_stream_pack(int C, int inner, int ch, int n_qkv, const float* h_w_out, const float* h_w1, const float* h_w2,
                            const float* h_w_qkv, uint16_t* h_dst);

@@ -73,9 +73,10 @@ static int run_attn(mtts_ctx* c, const AttnArgs& a0, hipStream_t s) {
     LAUNCHB(c, 1, attn_flops(a), attn_bytes(a), s, launch_attention(a, s));
     return 0;
 }
-// prefetch workgroups of the chain launch (tblock_chain.hip): one per XCD; MTTS_CHAIN_PF=<n> (0: none) for A/B runs
+// prefetch workgroups of the chain launch (tblock_chain.hip): two per XCD (one alone takes ~93 us for the 7 MB stream and is the tail
+// of the launches without a q|k|v phase: 16 instead of 8 = -0.15 ms of GEMM time per step); MTTS_CHAIN_PF=<n> (0: none) for A/B runs
 static int chain_prefetch_wgs() {
-    static const int n = [] { const char* e = getenv("MTTS_CHAIN_PF"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    static const int n = [] { const char* e = getenv("MTTS_CHAIN_PF"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
     return n;
 }
 // Launch plan of a chain launch over M rows (hidden chunk ch; qb_forced = MTTS_CHAIN_QB or 0): rows per workgroup and prefetch
@@ -87,7 +88,8 @@ static void chain_plan(int M, int ch, int qb_forced, int* qb, int* pf) {
     const bool fits32 = (M + 31) / 32 + want <= 256;
     *qb = (qb_forced == 32 || qb_forced == qb_big) ? qb_forced : (fits32 ? 32 : qb_big);
     const int nwg = (M + *qb - 1) / *qb;
-    *pf = (nwg <= 256 && nwg + want > 256) ? 0 : want;
+    *pf = want;
+    if (nwg <= 256 && nwg + *pf > 256) *pf = (want >= 8 && nwg + 8 <= 256) ? 8 : 0;
 }
 static int run_chain(mtts_ctx* c, const ChainArgs& a0, hipStream_t s) {
     ChainArgs a = a0;

@@ -169,7 +169,7 @@ def test_context_refuses_concurrent_use(lib, hparams):
 
 
 def test_chain_launch_plan_keeps_grids_to_one_round(lib):
-    """mtts_chain_plan (host arithmetic of the model's chain launches, default MTTS_CHAIN_PF = 8): 32-row workgroups while they and
+    """mtts_chain_plan (host arithmetic of the model's chain launches, default MTTS_CHAIN_PF = 16): 32-row workgroups while they and
     the prefetch workgroups are one round of the 256 CUs, 48-row ones beyond (B = 25: 8050 rows -> 168 + 8, not 252 + 8), and no
     prefetchers when they alone would push a one-round grid into a second round (B = 37: 249 workgroups)."""
     import ctypes, os
@@ -179,15 +179,15 @@ def test_chain_launch_plan_keeps_grids_to_one_round(lib):
         qb, pf = ctypes.c_int(0), ctypes.c_int(0)
         assert lib.mtts_chain_plan(M, ch, ctypes.byref(qb), ctypes.byref(pf)) == 0
         return qb.value, pf.value
-    assert plan(32 * 161) == (32, 8)              # the half-length level of B = 32 (when the threshold lets it through)
-    assert plan(7936) == (32, 8)                  # 248 + 8 = 256
-    assert plan(7937) == (48, 8)
-    assert plan(25 * 322) == (48, 8)
-    assert plan(32 * 322) == (48, 8)              # 215 + 8
-    assert plan(36 * 322) == (48, 8)              # 242 + 8
-    assert plan(37 * 322) == (48, 0)              # 249 workgroups: + 8 would be a second round
-    assert plan(64 * 322) == (48, 8)              # several rounds anyway
-    assert plan(5152, ch=128) == (32, 8) and plan(10304, ch=128) == (64, 8)
+    assert plan(32 * 161) == (32, 16)             # the half-length level of B = 32 (when the thresholds let it through)
+    assert plan(7680) == (32, 16)                 # 240 + 16 = 256
+    assert plan(7681) == (48, 16)
+    assert plan(25 * 322) == (48, 16)
+    assert plan(32 * 322) == (48, 16)             # 215 + 16
+    assert plan(36 * 322) == (48, 8)              # 242 workgroups: only eight prefetchers fit the round
+    assert plan(37 * 322) == (48, 0)              # 249 workgroups: none do
+    assert plan(64 * 322) == (48, 16)             # several rounds anyway
+    assert plan(5152, ch=128) == (32, 16) and plan(10304, ch=128) == (64, 16)
     assert lib.mtts_chain_plan(0, 256, None, None) != 0
 
 
