@@ -210,6 +210,8 @@ def main():
     n_dev = torch.cuda.device_count()
     if world > 1 and backend == "nccl" and n_dev < world:
         raise SystemExit(f"--gpus {world} needs {world} devices for RCCL (found {n_dev}); set MTTS_DIST_BACKEND=gloo to rehearse")
+    if world > n_dev:           # rehearsal: ranks share a card, and the pair form of the chain launch needs the chip to itself
+        os.environ.setdefault("MTTS_CHAIN_PAIR", "0")
     local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
