@@ -42,7 +42,8 @@ def _model(dev):
 def _worker(rank, world, port, n_utts, out_dir):
     import importlib
     sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHDYNAMO_DISABLE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHDYNAMO_DISABLE="1",
+                      MTTS_CHAIN_PAIR="0")          # two ranks share the card here: the pair form needs the chip to itself
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     hp, synthetic, model = _model(dev)
