@@ -209,7 +209,7 @@ struct ChainArgs {
     float* pair_part = nullptr;
     unsigned int* pair_flag = nullptr;
     unsigned int pair_epoch = 0;         // a value no earlier launch on these flags used
-    int pf_wgs = 0;                      // extra workgroups (lowest ids) that only touch the weight stream ahead of the others; 8 = one per XCD
+    int pf_wgs = 0;                      // extra workgroups (lowest ids) that only touch the weight stream ahead of the others; 8 = one per XCD, 16 = two (the model's default; the pair form takes 16: one per XCD and half)
     unsigned long long* kstamp = nullptr;// diagnostic builds only (-DMTTS_CHAIN_STAMP): 16 phase stamps of workgroup 0
 };
 // fragments per wave of the stream for (C, inner, hidden chunk, q|k|v width), incl. the padding the register ring may run into
