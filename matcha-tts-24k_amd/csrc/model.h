@@ -104,7 +104,7 @@ struct mtts_ctx {
     int chain_qb = 0;             // rows per workgroup (MTTS_CHAIN_QB at mtts_create; 0 = by shape)
     bool pair_on = true;          // pair form of the chain launch for levels below chain_min_rows (MTTS_CHAIN_PAIR=0 at mtts_create disables)
     unsigned int pair_epoch = 0;  // flag value of the latest pair launch (unique per launch)
-    int chain_min_rows = 6000;    // estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS):
+    int chain_min_rows = 5761;    // (= where the pair form's residency bound, 120 tiles of 48 rows, ends) estimator rows (B * T of a level) from which the chain replaces the four GEMM launches (MTTS_CHAIN_MIN_ROWS):
                                   // measured at width 384 -- 10304 rows: 138 vs ~160 us per block; 5152 rows: 100 vs ~92 us (profiles/r03_chain_*)
     mtts::DecW dec;
     mtts::EncW enc;
