@@ -1325,6 +1325,12 @@ mtts_ctx* mtts_create(const mtts_config* cfg) {
     { const char* e = getenv("MTTS_CHAIN_QB"); c->chain_qb = e ? atoi(e) : 0; }
     { const char* e = getenv("MTTS_CHAIN_MIN_ROWS"); if (e) c->chain_min_rows = atoi(e); }
     { const char* e = getenv("MTTS_CHAIN_PAIR"); c->pair_on = !(e && e[0] == '0'); }
+    if (c->pair_on) {          // the pair form's residency bound assumes the whole 256-CU chip: a partitioned or smaller device runs without it
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount < 256) c->pair_on = false;
+        (void)hipGetLastError();             // (no device at all -- the CPU-side packing tests -- leaves the setting as it is)
+    }
     return c;
 }
 
